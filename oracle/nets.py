@@ -1,0 +1,330 @@
+"""Network-level CPU restatement (plain torch fp32).  TEST INFRASTRUCTURE ONLY.
+
+The predictors are rebuilt from small layer tables; module attribute names are
+kept identical to the reference so that state_dict keys match one-for-one
+(key compatibility is part of the drop-in contract) and
+reference-generated weights load directly.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+# (name, cin, cout, k, stride) -- FlowNetS/FlowNetS.py:17-26
+FLOWNETS_ENCODER = [
+    ("conv1", 2, 64, 7, 2), ("conv2", 64, 128, 5, 2), ("conv3", 128, 256, 5, 2),
+    ("conv3_1", 256, 256, 3, 1), ("conv4", 256, 512, 3, 2), ("conv4_1", 512, 512, 3, 1),
+    ("conv5", 512, 512, 3, 2), ("conv5_1", 512, 512, 3, 1), ("conv6", 512, 1024, 3, 2),
+    ("conv6_1", 1024, 1024, 3, 1),
+]
+# decoder level -> (deconv cin, deconv cout, predict_flow cin) -- FlowNetS/FlowNetS.py:28-42
+FLOWNET_DECODER = {5: (1024, 512), 4: (1026, 256), 3: (770, 128), 2: (386, 64)}
+FLOWNET_PREDICT = {6: 1024, 5: 1026, 4: 770, 3: 386, 2: 194}
+
+
+def _conv_block(bn: bool, cin: int, cout: int, k: int = 3, stride: int = 1) -> nn.Sequential:
+    """FlowNetS/util.py:17-42 == flownet2/networks/submodules.py:7-18."""
+    layers: List[nn.Module] = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=not bn)]
+    if bn:
+        layers.append(nn.BatchNorm2d(cout))
+    layers.append(nn.LeakyReLU(0.1, inplace=True))
+    return nn.Sequential(*layers)
+
+
+def _crop_like(t: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+    """FlowNetS/util.py:75-79 (the cropping variant, not utils.py's no-op)."""
+    return t[:, :, : ref.shape[2], : ref.shape[3]]
+
+
+class _FlowNetDecoderMixin:
+    """Refinement decoder shared by FlowNetS and FlowNetC (FlowNetS.py:60-80,
+    flownet2/networks/FlowNetC.py:104-125)."""
+
+    def _build_decoder(self, bias: bool) -> None:
+        for lvl, (cin, cout) in FLOWNET_DECODER.items():
+            setattr(self, f"deconv{lvl}", nn.Sequential(
+                nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=bias), nn.LeakyReLU(0.1, inplace=True)))
+        for lvl, cin in FLOWNET_PREDICT.items():
+            setattr(self, f"predict_flow{lvl}", nn.Conv2d(cin, 2, 3, 1, 1, bias=bias))
+        for lvl in (6, 5, 4, 3):
+            setattr(self, f"upsampled_flow{lvl}_to_{lvl - 1}", nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=bias))
+
+    def _decode(self, skips: dict) -> dict:
+        """skips: {6: out_conv6, 5: .., 4: .., 3: .., 2: ..} -> {lvl: flow}."""
+        flows = {6: self.predict_flow6(skips[6])}
+        feat = skips[6]
+        for lvl in (5, 4, 3, 2):
+            up = _crop_like(getattr(self, f"upsampled_flow{lvl + 1}_to_{lvl}")(flows[lvl + 1]), skips[lvl])
+            dec = _crop_like(getattr(self, f"deconv{lvl}")(feat), skips[lvl])
+            feat = torch.cat((skips[lvl], dec, up), 1)
+            flows[lvl] = getattr(self, f"predict_flow{lvl}")(feat)
+        return flows
+
+
+class FlowNetS(nn.Module, _FlowNetDecoderMixin):
+    """FlowNetS/FlowNetS.py:10-93: 2-channel input, top flow hard-wired to
+    256x256 by an un-rescaled bilinear upsample of flow2."""
+
+    def __init__(self, batchNorm: bool = True):
+        super().__init__()
+        self.batchNorm = batchNorm
+        for name, cin, cout, k, s in FLOWNETS_ENCODER:
+            setattr(self, name, _conv_block(batchNorm, cin, cout, k, s))
+        self._build_decoder(bias=False)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight, 0.1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        c2 = self.conv2(self.conv1(x))
+        c3 = self.conv3_1(self.conv3(c2))
+        c4 = self.conv4_1(self.conv4(c3))
+        c5 = self.conv5_1(self.conv5(c4))
+        c6 = self.conv6_1(self.conv6(c5))
+        fl = self._decode({6: c6, 5: c5, 4: c4, 3: c3, 2: c2})
+        flow0 = ops.resize_bilinear(fl[2], (256, 256), align_corners=False)
+        if self.training:
+            return flow0, fl[2], fl[3], fl[4], fl[5], fl[6]
+        return flow0, fl[2]
+
+
+class Correlation(nn.Module):
+    """Stand-in module for the external correlation_package (see ops.correlation)."""
+
+    def __init__(self, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply):
+        super().__init__()
+        self.cfg = (pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
+
+    def forward(self, a, b):
+        return ops.correlation(a, b, *self.cfg)
+
+
+class FlowNetC(nn.Module, _FlowNetDecoderMixin):
+    """flownet2/networks/FlowNetC.py:13-130 (1-channel streams; biases ON for
+    deconv / predict_flow / flow upsamplers, xavier init)."""
+
+    def __init__(self, args=None, batchNorm: bool = True, div_flow: float = 20):
+        super().__init__()
+        self.batchNorm = batchNorm
+        self.div_flow = div_flow
+        self.conv1 = _conv_block(batchNorm, 1, 64, 7, 2)
+        self.conv2 = _conv_block(batchNorm, 64, 128, 5, 2)
+        self.conv3 = _conv_block(batchNorm, 128, 256, 5, 2)
+        self.conv_redir = _conv_block(batchNorm, 256, 32, 1, 1)
+        self.corr = Correlation(20, 1, 20, 1, 2, 1)
+        self.corr_activation = nn.LeakyReLU(0.1, inplace=True)
+        self.conv3_1 = _conv_block(batchNorm, 473, 256)
+        for name, cin, cout, k, s in FLOWNETS_ENCODER[4:]:
+            setattr(self, name, _conv_block(batchNorm, cin, cout, k, s))
+        self._build_decoder(bias=True)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                if m.bias is not None:
+                    nn.init.uniform_(m.bias)
+                nn.init.xavier_uniform_(m.weight)
+
+    def forward(self, x):
+        a, b = x[:, 0:1], x[:, 1:2]
+        c1a = self.conv1(a)
+        c2a = self.conv2(c1a)
+        c3a = self.conv3(c2a)
+        c3b = self.conv3(self.conv2(self.conv1(b)))
+        corr = self.corr_activation(self.corr(c3a, c3b))
+        c3 = self.conv3_1(torch.cat((self.conv_redir(c3a), corr), 1))
+        c4 = self.conv4_1(self.conv4(c3))
+        c5 = self.conv5_1(self.conv5(c4))
+        c6 = self.conv6_1(self.conv6(c5))
+        fl = self._decode({6: c6, 5: c5, 4: c4, 3: c3, 2: c2a})
+        if self.training:
+            return fl[2], fl[3], fl[4], fl[5], fl[6]
+        return (fl[2],)
+
+
+# PWC-DC-Net -----------------------------------------------------------------
+PWC_PYRAMID = [(1, 16), (16, 32), (32, 64), (64, 96), (96, 128), (128, 196)]  # PWCNet.py:50-67
+PWC_DENSE = [128, 128, 96, 64, 32]                                            # PWCNet.py:73-80
+PWC_FLOW_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}                           # PWCNet.py:214-258
+
+
+def _pwc_conv(cin, cout, k=3, stride=1, padding=1, dilation=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, padding, dilation, bias=True), nn.LeakyReLU(0.1))
+
+
+class PWCDCNet(nn.Module):
+    """PWC/models/PWCNet.py:38-279."""
+
+    def __init__(self, md: int = 4):
+        super().__init__()
+        names = {1: ("conv1a", "conv1aa", "conv1b"), 2: ("conv2a", "conv2aa", "conv2b"),
+                 3: ("conv3a", "conv3aa", "conv3b"), 4: ("conv4a", "conv4aa", "conv4b"),
+                 5: ("conv5a", "conv5aa", "conv5b"), 6: ("conv6aa", "conv6a", "conv6b")}
+        self._pyr_names = names
+        for lvl, (cin, cout) in enumerate(PWC_PYRAMID, start=1):
+            n0, n1, n2 = names[lvl]
+            setattr(self, n0, _pwc_conv(cin, cout, 3, 2))
+            setattr(self, n1, _pwc_conv(cout, cout, 3, 1))
+            setattr(self, n2, _pwc_conv(cout, cout, 3, 1))
+        self.corr = Correlation(md, 1, md, 1, 1, 1)
+        self.leakyRELU = nn.LeakyReLU(0.1)
+        nd = (2 * md + 1) ** 2
+        dd = np.cumsum(PWC_DENSE)
+        feat_c = {6: 0, 5: 128, 4: 96, 3: 64, 2: 32}
+        for lvl in (6, 5, 4, 3, 2):
+            od = nd if lvl == 6 else nd + feat_c[lvl] + 4
+            cin = od
+            for j, cout in enumerate(PWC_DENSE):
+                setattr(self, f"conv{lvl}_{j}", _pwc_conv(cin, cout))
+                cin = od + int(dd[j])
+            setattr(self, f"predict_flow{lvl}", nn.Conv2d(cin, 2, 3, 1, 1, bias=True))
+            if lvl > 2:
+                setattr(self, f"deconv{lvl}", nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True))
+                setattr(self, f"upfeat{lvl}", nn.ConvTranspose2d(cin, 2, 4, 2, 1, bias=True))
+        self.deconv2 = nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True)
+        self.deconv1 = nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True)
+        self.deconv0 = nn.ConvTranspose2d(2, 2, 4, 4, 0, bias=True)
+        od = nd + 32 + 4
+        dc = [(od + int(dd[4]), 128, 1), (128, 128, 2), (128, 128, 4), (128, 96, 8), (96, 64, 16), (64, 32, 1)]
+        for i, (cin, cout, d) in enumerate(dc, start=1):
+            setattr(self, f"dc_conv{i}", _pwc_conv(cin, cout, 3, 1, d, d))
+        self.dc_conv7 = nn.Conv2d(32, 2, 3, 1, 1, bias=True)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight.data, mode="fan_in")
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def warp(self, x, flo):
+        return ops.pwc_warp(x, flo)
+
+    def _dense(self, lvl, x):
+        for j in range(5):
+            x = torch.cat((getattr(self, f"conv{lvl}_{j}")(x), x), 1)
+        return x
+
+    def forward(self, x):
+        feats = {0: (x[:, :1], x[:, 1:])}
+        for lvl in range(1, 7):
+            fa, fb = feats[lvl - 1]
+            for n in self._pyr_names[lvl]:
+                fa, fb = getattr(self, n)(fa), getattr(self, n)(fb)
+            feats[lvl] = (fa, fb)
+        flows = {}
+        x = self._dense(6, self.leakyRELU(self.corr(*feats[6])))
+        flows[6] = self.predict_flow6(x)
+        up_flow, up_feat = self.deconv6(flows[6]), self.upfeat6(x)
+        for lvl in (5, 4, 3, 2):
+            c1, c2 = feats[lvl]
+            corr = self.leakyRELU(self.corr(c1, self.warp(c2, up_flow * PWC_FLOW_SCALE[lvl])))
+            x = self._dense(lvl, torch.cat((corr, c1, up_flow, up_feat), 1))
+            flows[lvl] = getattr(self, f"predict_flow{lvl}")(x)
+            if lvl > 2:
+                up_flow = getattr(self, f"deconv{lvl}")(flows[lvl])
+                up_feat = getattr(self, f"upfeat{lvl}")(x)
+        y = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(x))))
+        flows[2] = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(y)))
+        flows[1] = self.deconv2(flows[2])
+        flows[0] = self.deconv1(flows[1])
+        return tuple(flows[i] for i in range(7))
+
+
+# registration wrapper ---------------------------------------------------------
+class OpticalFlowReg(nn.Module):
+    """models.py:208-289 with the build's API fix for SURVEY Q1:
+    forward(x, segs=None); the seg / grid branch only runs when segs is given
+    and the deformation-grid image is broadcast over the batch."""
+
+    def __init__(self, conv_predictor: str = "flownets"):
+        super().__init__()
+        if "pwc" in conv_predictor:
+            self.predictor = PWCDCNet(md=4)
+        elif "flownetc" in conv_predictor:
+            self.predictor = FlowNetC(batchNorm=True)
+        else:
+            self.predictor = FlowNetS(batchNorm=True)
+
+    def stn(self, flow, frame):
+        return ops.stn(flow, frame)
+
+    def forward(self, x, segs=None):
+        flows = self.predictor(x)
+        moving = x[:, 1:2]
+        warped = [self.stn(f, moving) for f in flows]
+        if segs is None:
+            return flows, warped, 0, 0
+        B = x.shape[0]
+        warped_segs = self.stn(flows[0], segs[:, 1:2])
+        grid = ops.grid_generator().view(1, 1, 256, 256).expand(B, 1, 256, 256)
+        warped_grid = self.stn(flows[0], grid)
+        return flows, warped, ops.seg_round(warped_segs.detach()), warped_grid
+
+
+class AffModel(nn.Module):
+    """models.py:156-191 (3-D affine registration net, 256x256x176 hard-wired
+    through fc in_features; `depth_features` lets tests run a scaled-down copy)."""
+
+    def __init__(self, fc_in: int = 176 * 512):
+        super().__init__()
+        spec = [(2, 16, 7, (2, 2, 1)), (16, 32, 5, (2, 2, 1)), (32, 64, 3, 2), (64, 128, 3, 2),
+                (128, 256, 3, 2), (256, 512, 3, 2)]
+        for i, (cin, cout, k, s) in enumerate(spec, start=1):
+            setattr(self, f"conv{i}", nn.Sequential(nn.Conv3d(cin, cout, k, s, (k - 1) // 2), nn.ReLU(True)))
+        self.flat = nn.Flatten()
+        self.fc = nn.Linear(fc_in, 12)
+
+    def forward(self, x):
+        b = x.shape[0]
+        moving = x[:, 1:]
+        h = x
+        for i in range(1, 7):
+            h = getattr(self, f"conv{i}")(h)
+        para = self.fc(self.flat(h)).view(b, 3, 4)
+        return para, ops.affine_grid_sample_3d(moving, para)
+
+
+def analytic_weights_(model: nn.Module, scale: float = 1.0) -> None:
+    """Deterministic, RNG-free weights so 150 MB checkpoints never need
+    committing: conv weights ~ kaiming-sized sinusoids, BN affine near (1, 0),
+    running stats near (0, 1).  gen_golden.py applies this same function to the
+    reference model (state_dict keys match), so both sides get equal weights."""
+    with torch.no_grad():
+        for li, (name, t) in enumerate(model.state_dict().items()):
+            n = t.numel()
+            idx = torch.arange(n, dtype=torch.float64)
+            if name.endswith("num_batches_tracked"):
+                continue
+            if t.dim() >= 3:  # conv / deconv weights
+                fan_in = n // t.shape[0]
+                amp = scale * (2.0 / max(fan_in, 1)) ** 0.5 * 1.2
+                vals = amp * torch.sin(0.37 * idx + 0.11 * li) * torch.cos(0.013 * idx + li)
+            elif name.endswith("running_var"):
+                vals = 1.0 + 0.2 * torch.sin(0.5 * idx + li)
+            elif name.endswith("running_mean"):
+                vals = 0.05 * torch.sin(0.3 * idx + li)
+            elif name.endswith("weight") and t.dim() == 1:  # BN gamma
+                vals = 1.0 + 0.1 * torch.sin(0.7 * idx + li)
+            elif t.dim() == 2:  # linear
+                vals = 1e-3 * torch.sin(0.37 * idx + li)
+            else:  # biases
+                vals = 0.02 * torch.sin(0.9 * idx + li)
+            t.copy_(vals.reshape(t.shape).to(t.dtype))
+
+
+def analytic_input(shape: Sequence[int], seed: int = 0, lo: float = 0.0, hi: float = 1.0) -> torch.Tensor:
+    """RNG-free pseudo-image: smooth sinusoid mix + a hashed fine-grain term."""
+    n = int(np.prod(shape))
+    i = torch.arange(n, dtype=torch.float64)
+    smooth = 0.5 + 0.25 * torch.sin(0.0123 * i + seed) + 0.15 * torch.cos(0.00071 * i * (1 + 0.1 * seed))
+    noise = torch.frac(torch.sin(i * 12.9898 + seed * 78.233) * 43758.5453).abs() * 0.1
+    v = (smooth + noise).clamp(0, 1) * (hi - lo) + lo
+    return v.reshape(*shape).to(torch.float32)
