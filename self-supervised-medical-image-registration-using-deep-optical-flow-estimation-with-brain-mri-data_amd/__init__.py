@@ -1,0 +1,11 @@
+"""mireg -- MI355X-native registration hot path.
+
+Public surface mirrors the reference's Python API for the hot path:
+  opticalFlowReg, FlowNetS, FlowNetC, PWCDCNet, Correlation, OFEloss, stn, dice_average
+Everything computes through libmireg_hip.so (hand-written gfx950 kernels); nothing here falls
+back to ATen/MIOpen or to the CPU oracle.
+"""
+from . import _lib  # noqa: F401
+from .ops import OFEloss, dice_average, dice_batch, resize_bilinear, seg_round, stn  # noqa: F401
+
+__all__ = ["OFEloss", "dice_average", "dice_batch", "resize_bilinear", "seg_round", "stn"]

@@ -1,0 +1,5 @@
+#include "../../include/mireg.h"
+extern "C" {
+int mireg_version(void) { return 1; }
+const char* mireg_arch(void) { return "gfx950"; }
+}

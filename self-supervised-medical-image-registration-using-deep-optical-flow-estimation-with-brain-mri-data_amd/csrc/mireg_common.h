@@ -1,0 +1,61 @@
+// mireg_common.h -- device-side helpers shared by the gfx950 kernels.
+// wave = 64 lanes everywhere (CDNA4); no 32-lane assumptions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MIREG_OK 0
+#define MIREG_ERR_ARG (-1)      // bad shape / stride / null pointer
+#define MIREG_ERR_LAUNCH (-2)   // hipLaunch / hipGetLastError failure
+#define MIREG_ERR_UNSUPPORTED (-3)
+
+#define MIREG_CHECK_ARG(cond) do { if (!(cond)) return MIREG_ERR_ARG; } while (0)
+#define MIREG_LAUNCH_RET() do { return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH; } while (0)
+
+namespace mireg {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Block-wide sum of N per-thread floats; result valid in thread 0.
+// red must hold N * (blockDim.x / 64) floats of LDS.
+template <int N>
+__device__ __forceinline__ void block_sum(float (&v)[N], float* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[wid * N + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] += red[w * N + i];
+    }
+  }
+}
+
+// Charbonnier penalty (x^2 + eps^2)^0.25 with eps = 1e-9 (reference loss.py:33-35)
+__device__ __forceinline__ float charb(float d) { return sqrtf(sqrtf(d * d + 1e-18f)); }
+// d/dd of the above: 0.5 * d * (d^2 + eps^2)^(-0.75)
+__device__ __forceinline__ float charb_grad(float d) {
+  const float t = d * d + 1e-18f;
+  const float r = rsqrtf(t);           // t^-0.5
+  return 0.5f * d * r * sqrtf(r);      // t^-0.75
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+}  // namespace mireg
