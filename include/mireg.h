@@ -77,6 +77,89 @@ int mireg_seg_round(const float* in, float* out, long n, hipStream_t stream);
 int mireg_dice(const float* y_true, const float* y_pred, float* counts, float* dice, int B, long n,
                hipStream_t stream);
 
+
+/* ---- K1-K4: implicit-GEMM convolution family on MFMA ------------------------------------- */
+/* One descriptor drives three contractions (all NHWC, pixel stride `ld` in elements, so producers
+ * write straight into channel slices of concat buffers -- replaces torch.cat, FlowNetS.py:64-79):
+ *   mireg_conv_gemm  FWD   : Conv2d forward      (FlowNetS/util.py:17-46, PWCNet.py:24-31)
+ *                    DGRAD : Conv2d backward-data == ConvTranspose2d forward
+ *                            (FlowNetS/util.py:49-55, FlowNetS.py:39-42, PWCNet.py:33-34); the host
+ *                            issues one launch per output-pixel parity class for stride 2
+ *   mireg_conv_wgrad WGRAD : Conv2d backward-weights (autograd of the above)
+ * GEMM view of mireg_conv_gemm: rows = logical grid (n_img, g_H, g_W); K = (ty, tx, c) with
+ *   input pixel iy = gy*mul_y + off_y + ty*step_y (same in x), zero outside [0,x_H)x[0,x_W);
+ *   cols = N output channels; weights packed [N][w_ld] with k = (ty*taps_x + tx)*x_C + c.
+ * Output pixel of row (img, gy, gx) is (gy*y_mul_y + y_off_y, gx*y_mul_x + y_off_x) in a y_H x y_W
+ * image; y (dtype `dtype`) and/or y32 (fp32) receive act(acc + bias) [+ previous y if accumulate].
+ * split_k > 1: partial sums go to slab[split_k][M][N] (fp32) and a second pass finishes.
+ * mireg_conv_wgrad reuses the struct: y/y_ld = dy rows over the same logical grid with N = Cout
+ * channels, x = the forward input; result slab[split_k][N][taps*x_C] (fp32).
+ * x_C, x_ld, w_ld, y_ld (wgrad) must be multiples of 8 (bf16) / 4 (fp32); pad channels must hold zeros. */
+typedef struct mireg_conv_desc {
+  const void* x; long x_ld; int x_H, x_W, x_C;
+  int taps_y, taps_x;
+  int mul_y, mul_x, off_y, off_x, step_y, step_x;
+  int g_H, g_W, n_img;
+  const void* w; long w_ld; int N;
+  void* y; long y_ld; int y_H, y_W, y_mul_y, y_mul_x, y_off_y, y_off_x;
+  float* y32; long y32_ld;
+  const float* bias; float slope; int accumulate; int dtype;
+  int split_k; float* slab;
+} mireg_conv_desc;
+int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream);
+int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);
+
+
+/* ---- weight layout plumbing (torch layout <-> GEMM layouts), one launch for a table of jobs ---- */
+/* pack: dst[row][(ty*ntx+tx)*Cpad + c] = W[co][ci][ky0+sy*ty][kx0+sx*tx] (W = torch Conv2d layout
+ * [Co][Ci][kh][kw] fp32, zero in every pad slot); kind 0: row=co,c=ci (FWD pack); kind 1: row=ci,c=co
+ * (DGRAD pack, one job per output-pixel parity class).  ConvTranspose2d weights [Cin][Cout][kh][kw]
+ * are the Conv2d weights of the adjoint convolution, so the same two packs serve deconvolutions.
+ * unpack: grad[co][ci][ky][kx] (+)= sum_z slab[z][co][(ky*kw+kx)*Cpad + ci]; there src = slab,
+ * dst = grad, rows = Co, ld = kh*kw*Cpad, sy = number of split-K slabs, kind = accumulate flag. */
+typedef struct mireg_pack_job {
+  const float* src; void* dst;
+  int Co, Ci, kh, kw;
+  int kind, Cpad, ky0, kx0, sy, sx, nty, ntx;
+  long ld; int rows;
+} mireg_pack_job;
+int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int dtype, hipStream_t stream);
+int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, hipStream_t stream);
+
+/* ---- K1 tail: BatchNorm2d (batch statistics in train mode) + LeakyReLU, FlowNetS/util.py:17-30 ---- */
+/* y is the raw convolution output [M][ld_y]; ss = [scale | shift | mean | rstd] (4*C floats);
+ * sums = 2*C doubles of workspace (zeroed inside). */
+int mireg_bn_stats(const void* y, long ld_y, long M, int C, double* sums, int dtype, hipStream_t stream);
+int mireg_bn_finalize(const double* sums, long M, int C, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, int training,
+                      float* ss, hipStream_t stream);
+int mireg_bn_apply(const void* y, long ld_y, void* out, long ld_o, const float* ss, long M, int C, float slope,
+                   int dtype, hipStream_t stream);
+/* da = gradient wrt the activated output; dy = gradient wrt the raw convolution output */
+int mireg_bn_bwd(const void* y, long ld_y, const void* da, long ld_da, void* dy, long ld_dy, const float* ss,
+                 double* sums, float* dgamma, float* dbeta, int acc_param_grads, long M, int C, float slope,
+                 int dtype, hipStream_t stream);
+int mireg_lrelu_bwd(void* g, long ld_g, const void* a, long ld_a, long M, int C, float slope, int dtype,
+                    hipStream_t stream);
+
+/* ---- dtype / layout staging ---------------------------------------------------------------- */
+int mireg_cast_from_f32(void* dst, long ld_d, const float* src, long ld_s, long M, int C, float alpha, float beta,
+                        int dtype, hipStream_t stream);
+int mireg_cast_to_f32(float* dst, long ld_d, const void* src, long ld_s, long M, int C, float alpha, float beta,
+                      int dtype, hipStream_t stream);
+/* x[:, c0:c0+nc] of an NCHW fp32 batch (train.py:44-46 hands NCHW) -> NHWC rows with pixel stride ld */
+int mireg_nchw_to_nhwc(const float* src, void* dst, int B, int Ctot, int c0, int nc, long HW, long ld, int dtype,
+                       hipStream_t stream);
+/* bias gradients: out[c] (+)= sum_m g[m][c] */
+int mireg_colsum(const void* g, long ld, long M, int C, float* out, int accumulate, int dtype, hipStream_t stream);
+
+/* ---- K20: Adam exactly as train.py:129 builds it (betas .9/.999, eps = lrMin = 1e-4) ---------- */
+typedef struct mireg_adam_job { float* p; const float* g; float* m; float* v; long n; } mireg_adam_job;
+/* *step_dev is incremented on device first (graph-replayable); grad_scale multiplies every gradient
+ * (1/world_size after a sum all-reduce). */
+int mireg_adam_step(const mireg_adam_job* jobs_dev, int njobs, int* step_dev, float lr, float beta1, float beta2,
+                    float eps, float grad_scale, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

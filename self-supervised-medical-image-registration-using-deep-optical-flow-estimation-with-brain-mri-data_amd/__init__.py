@@ -7,5 +7,6 @@ back to ATen/MIOpen or to the CPU oracle.
 """
 from . import _lib  # noqa: F401
 from .ops import OFEloss, dice_average, dice_batch, resize_bilinear, seg_round, stn  # noqa: F401
+from .flownets import FlowNetS  # noqa: F401
 
-__all__ = ["OFEloss", "dice_average", "dice_batch", "resize_bilinear", "seg_round", "stn"]
+__all__ = ["FlowNetS", "OFEloss", "dice_average", "dice_batch", "resize_bilinear", "seg_round", "stn"]

@@ -1,0 +1,489 @@
+// conv_gemm.hip -- implicit-GEMM convolution family on the gfx950 matrix cores (K1-K4).
+//
+// One gather-GEMM kernel serves every dense contraction of the predictors:
+//   FWD   conv forward                (FlowNetS/util.py:17-46, PWC/models/PWCNet.py:24-31)
+//   DGRAD conv backward-data == ConvTranspose2d forward (FlowNetS/util.py:49-55, PWCNet.py:33-34),
+//         decomposed per output-pixel parity for stride 2 so no MAC is wasted on zero taps
+//   WGRAD conv backward-weights (second kernel: reduction over pixels)
+// Activations are NHWC with a pixel stride (ld) so producers write straight into channel slices of
+// the concat buffers (no torch.cat copies, K5).  Operands are bf16 (v_mfma_f32_32x32x16_bf16) or
+// fp32 (v_mfma_f32_32x32x2_f32, exact fp32: the parity path); accumulation is always fp32.
+//
+// Tiling: 256 threads = 4 waves, block tile BM x BN x (64 bytes of K), wave tile of 32x32 MFMA
+// sub-tiles, LDS double buffer with register-staged prefetch (global -> VGPR -> LDS), rows padded
+// to 80 B so that ds_read_b128 fragment reads are bank-conflict free.
+#include "mireg_common.h"
+#include "../../include/mireg.h"
+
+using namespace mireg;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+struct alignas(16) Chunk { uint32_t w[4]; };
+
+template <typename T> struct Cfg;
+template <> struct Cfg<float>  { static constexpr int CPC = 4, BK = 16; };   // elements per 16-B chunk, K per step
+template <> struct Cfg<__bf16> { static constexpr int CPC = 8, BK = 32; };
+
+constexpr int kRowB = 80;   // LDS row pitch of the [row][k] tiles: 64 B of K + 16 B pad
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// =====================================================================================================
+// FWD / DGRAD: C[m][n] = sum_k A[m][k] * W[n][k], rows m = output pixels (gathered), cols n = channels
+// =====================================================================================================
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256)
+conv_gemm_kernel(const mireg_conv_desc p) {
+  constexpr int CPC = Cfg<T>::CPC, BK = Cfg<T>::BK;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_CH = BM / 64;
+  constexpr int B_CH = (BN + 63) / 64;
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "bad tile");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * kRowB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int gHW = p.g_H * p.g_W;
+  const int M = p.n_img * gHW;
+  const int K = p.taps_y * p.taps_x * p.x_C;
+  const int nk_total = (K + BK - 1) / BK;
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.split_k > 1) {
+    const int per = (nk_total + p.split_k - 1) / p.split_k;
+    kt_begin = blockIdx.z * per;
+    kt_end = min(nk_total, kt_begin + per);
+  }
+
+  // ---- loader state ---------------------------------------------------------------------------
+  const int kc = tid & 3, lrow = tid >> 2;
+  long a_base[A_CH];
+  int a_iy0[A_CH], a_ix0[A_CH];
+  bool a_ok[A_CH];
+#pragma unroll
+  for (int c = 0; c < A_CH; ++c) {
+    const int m = m0 + lrow + 64 * c;
+    a_ok[c] = m < M;
+    const int mm = a_ok[c] ? m : 0;
+    const int img = mm / gHW, rem = mm - img * gHW;
+    const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
+    a_base[c] = (long)img * p.x_H * p.x_W * p.x_ld;
+    a_iy0[c] = gy * p.mul_y + p.off_y;
+    a_ix0[c] = gx * p.mul_x + p.off_x;
+  }
+  const int cpt = p.x_C / CPC;              // chunks per tap
+  int ty, tx, cc;
+  {
+    const int q = kt_begin * 4 + kc;
+    const int tap = q / cpt;
+    cc = q - tap * cpt;
+    ty = tap / p.taps_x;
+    tx = tap - ty * p.taps_x;
+  }
+  const T* __restrict__ xp = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wp = reinterpret_cast<const T*>(p.w);
+  Chunk ra[A_CH], rb[B_CH];
+  const Chunk zero = {{0u, 0u, 0u, 0u}};
+
+  auto load_tiles = [&](int kt) {
+    const bool kvalid = ty < p.taps_y;
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) {
+      const int iy = a_iy0[c] + ty * p.step_y, ix = a_ix0[c] + tx * p.step_x;
+      const bool ok = a_ok[c] && kvalid && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
+      ra[c] = ok ? *reinterpret_cast<const Chunk*>(xp + a_base[c] + ((long)iy * p.x_W + ix) * p.x_ld + cc * CPC) : zero;
+    }
+    const int k = kt * BK + kc * CPC;
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) {
+      const int nl = lrow + 64 * c, n = n0 + nl;
+      const bool ok = nl < BN && n < p.N && k < K;
+      rb[c] = ok ? *reinterpret_cast<const Chunk*>(wp + (long)n * p.w_ld + k) : zero;
+    }
+    cc += 4;                                 // advance this thread's chunk by one K-step
+    while (cc >= cpt) { cc -= cpt; if (++tx == p.taps_x) { tx = 0; ++ty; } }
+  };
+  auto store_tiles = [&](int buf) {
+    unsigned char* As = smem + buf * (BM + BN) * kRowB;
+    unsigned char* Bs = As + BM * kRowB;
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) *reinterpret_cast<Chunk*>(As + (lrow + 64 * c) * kRowB + kc * 16) = ra[c];
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c)
+      if (lrow + 64 * c < BN) *reinterpret_cast<Chunk*>(Bs + (lrow + 64 * c) * kRowB + kc * 16) = rb[c];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool more = kt + 1 < kt_end;
+      if (more) load_tiles(kt + 1);
+      const unsigned char* As = smem + cur * (BM + BN) * kRowB + (wm * WTM + r) * kRowB;
+      const unsigned char* Bs = smem + cur * (BM + BN) * kRowB + BM * kRowB + (wn * WTN + r) * kRowB;
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 af[TM], bfr[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * kRowB + ks * 32 + h * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * kRowB + ks * 32 + h * 16);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
+        // fp32 operands: lane (r,h) takes K slots {8g+4h .. 8g+4h+3}; MFMA t of group g contracts slot t of
+        // both halves -- the same K permutation on A and B, so the sum over K is unchanged.
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          f32x4 af[TM], bfr[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * kRowB + g * 32 + h * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * kRowB + g * 32 + h * 16);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bfr[j][t], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // 32x32 accumulator: column n = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  T* __restrict__ yp = reinterpret_cast<T*>(p.y);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (m >= M) continue;
+      if (p.split_k > 1) {
+        float* dst = p.slab + ((long)blockIdx.z * M + m) * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * WTN + j * 32 + r;
+          if (n < p.N) dst[n] = acc[i][j][e];
+        }
+        continue;
+      }
+      const int img = m / gHW, rem = m - img * gHW;
+      const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
+      const long pix = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + r;
+        if (n >= p.N) continue;
+        float v = acc[i][j][e];
+        if (p.bias) v += p.bias[n];
+        v = v > 0.f ? v : v * p.slope;
+        if (yp) {
+          T* d = yp + pix * p.y_ld + n;
+          if (p.accumulate) v += to_f32(*d);
+          *d = from_f32<T>(v);
+        }
+        if (p.y32) p.y32[pix * p.y32_ld + n] = v;
+      }
+    }
+  }
+}
+
+// split-K second pass: y = act(sum_z slab[z] + bias) with the same pixel mapping as the main epilogue
+template <typename T>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const mireg_conv_desc p) {
+  const int gHW = p.g_H * p.g_W;
+  const long M = (long)p.n_img * gHW, total = M * p.N;
+  T* __restrict__ yp = reinterpret_cast<T*>(p.y);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / p.N;
+    const int n = (int)(i - m * p.N);
+    float v = 0.f;
+    for (int z = 0; z < p.split_k; ++z) v += p.slab[(long)z * total + i];
+    if (p.bias) v += p.bias[n];
+    v = v > 0.f ? v : v * p.slope;
+    const int img = (int)(m / gHW), rem = (int)(m - (long)img * gHW);
+    const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
+    const long pix = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
+    if (yp) {
+      T* d = yp + pix * p.y_ld + n;
+      if (p.accumulate) v += to_f32(*d);
+      *d = from_f32<T>(v);
+    }
+    if (p.y32) p.y32[pix * p.y32_ld + n] = v;
+  }
+}
+
+// =====================================================================================================
+// WGRAD: dW[co][kidx] = sum_pix dy[pix][co] * x[gather(pix, tap(kidx))][c(kidx)]   (fp32 slabs out)
+// LDS tiles are [pixel][channel] (channel-contiguous, as both operands sit in HBM); bf16 fragments are
+// formed with the gfx950 transposing LDS read (ds_read_b64_tr_b16), fp32 fragments with plain b32 reads.
+// =====================================================================================================
+template <typename T, int BM, int BN>
+__global__ void __launch_bounds__(256)
+conv_wgrad_kernel(const mireg_conv_desc p) {
+  constexpr int CPC = Cfg<T>::CPC, BK = Cfg<T>::BK;
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+  constexpr int LDA = BM + (sizeof(T) == 2 ? 32 : 0);   // elements; bf16 pitch 320 B == 64 mod 256 (tr-read friendly)
+  constexpr int LDB = BN + (sizeof(T) == 2 ? 32 : 0);
+  constexpr int A_CPR = BM / CPC, B_CPR = BN / CPC;     // chunks per pixel row
+  constexpr int A_CH = BK * A_CPR / 256, B_CH = BK * B_CPR / 256;
+  static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) T smem[2 * BK * (LDA + LDB)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int Ktot = p.taps_y * p.taps_x * p.x_C;          // GEMM N
+  const int tiles_n = (Ktot + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int gHW = p.g_H * p.g_W;
+  const int P = p.n_img * gHW;                            // reduction length (pixels)
+  const int nk_total = (P + BK - 1) / BK;
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.split_k > 1) {
+    const int per = (nk_total + p.split_k - 1) / p.split_k;
+    kt_begin = blockIdx.z * per;
+    kt_end = min(nk_total, kt_begin + per);
+  }
+  const T* __restrict__ dyp = reinterpret_cast<const T*>(p.y);
+  const T* __restrict__ xp = reinterpret_cast<const T*>(p.x);
+
+  // loader state: A chunk = (pixel row, co chunk); B chunk = (pixel row, kidx chunk -> fixed tap / channel)
+  int a_prow[A_CH], a_col[A_CH];
+  bool a_cok[A_CH];
+#pragma unroll
+  for (int c = 0; c < A_CH; ++c) {
+    const int id = tid + 256 * c;
+    a_prow[c] = id / A_CPR;
+    a_col[c] = (id - a_prow[c] * A_CPR) * CPC;
+    a_cok[c] = m0 + a_col[c] < (p.N + CPC - 1) / CPC * CPC;   // dy rows are readable up to the CPC pad
+  }
+  int b_prow[B_CH], b_col[B_CH], b_ty[B_CH], b_tx[B_CH], b_ch[B_CH];
+  bool b_cok[B_CH];
+#pragma unroll
+  for (int c = 0; c < B_CH; ++c) {
+    const int id = tid + 256 * c;
+    b_prow[c] = id / B_CPR;
+    b_col[c] = (id - b_prow[c] * B_CPR) * CPC;
+    const int n = n0 + b_col[c];
+    b_cok[c] = n < Ktot;
+    const int tap = (b_cok[c] ? n : 0) / p.x_C;
+    b_ch[c] = (b_cok[c] ? n : 0) - tap * p.x_C;
+    b_ty[c] = tap / p.taps_x;
+    b_tx[c] = tap - b_ty[c] * p.taps_x;
+  }
+  Chunk ra[A_CH], rb[B_CH];
+  const Chunk zero = {{0u, 0u, 0u, 0u}};
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) {
+      const int pix = kt * BK + a_prow[c];
+      const bool ok = a_cok[c] && pix < P;
+      ra[c] = ok ? *reinterpret_cast<const Chunk*>(dyp + (long)pix * p.y_ld + m0 + a_col[c]) : zero;
+    }
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) {
+      const int pix = kt * BK + b_prow[c];
+      bool ok = b_cok[c] && pix < P;
+      const int pp = ok ? pix : 0;
+      const int img = pp / gHW, rem = pp - img * gHW;
+      const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
+      const int iy = gy * p.mul_y + p.off_y + b_ty[c] * p.step_y, ix = gx * p.mul_x + p.off_x + b_tx[c] * p.step_x;
+      ok = ok && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
+      rb[c] = ok ? *reinterpret_cast<const Chunk*>(xp + (((long)img * p.x_H + iy) * p.x_W + ix) * p.x_ld + b_ch[c]) : zero;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    T* At = smem + buf * BK * (LDA + LDB);
+    T* Bt = At + BK * LDA;
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) *reinterpret_cast<Chunk*>(At + a_prow[c] * LDA + a_col[c]) = ra[c];
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) *reinterpret_cast<Chunk*>(Bt + b_prow[c] * LDB + b_col[c]) = rb[c];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool more = kt + 1 < kt_end;
+      if (more) load_tiles(kt + 1);
+      const T* At = smem + cur * BK * (LDA + LDB);
+      const T* Bt = At + BK * LDA;
+      if constexpr (sizeof(T) == 2) {
+        // transposing read: 16-lane group g covers columns 16*(g&1).., rows 8*(g>>1) + 4*t + q of a 16-pixel step
+        const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+        const int rowoff = 8 * (g >> 1) + q, coloff = 16 * (g & 1) + 4 * pp;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 af[TM], bfr[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const T* base = At + (ks * 16 + rowoff) * LDA + wm * WTM + i * 32 + coloff;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + 4 * LDA));
+            const __attribute__((ext_vector_type(8))) short v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            af[i] = __builtin_bit_cast(bf16x8, v);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const T* base = Bt + (ks * 16 + rowoff) * LDB + wn * WTN + j * 32 + coloff;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + 4 * LDB));
+            const __attribute__((ext_vector_type(8))) short v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bfr[j] = __builtin_bit_cast(bf16x8, v);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < BK / 2; ++t) {
+          float af[TM], bfr[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = to_f32(At[(2 * t + h) * LDA + wm * WTM + i * 32 + r]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bfr[j] = to_f32(Bt[(2 * t + h) * LDB + wn * WTN + j * 32 + r]);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // epilogue: fp32 slab [z][Cout][Ktot]
+  const int Cout = p.N;
+  float* __restrict__ slab = p.slab + (long)blockIdx.z * Cout * Ktot;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (m >= Cout) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + r;
+        if (n < Ktot) slab[(long)m * Ktot + n] = acc[i][j][e];
+      }
+    }
+}
+
+template <typename T>
+int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
+  const long M = (long)p.n_img * p.g_H * p.g_W;
+  const int z = p.split_k > 1 ? p.split_k : 1;
+  if (p.N > 64) {
+    dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 127) / 128)), 1, z);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, stream, p);
+  } else if (p.N > 32) {
+    dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 63) / 64)), 1, z);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, stream, p);
+  } else {
+    dim3 grid((unsigned)((M + 127) / 128), 1, z);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1>), grid, dim3(256), 0, stream, p);
+  }
+  if (z > 1) {
+    const long total = M * p.N;
+    long g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)g), dim3(256), 0, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
+}
+
+template <typename T>
+int launch_wgrad(const mireg_conv_desc& p, hipStream_t stream) {
+  const int Cout = p.N;
+  const int Ktot = p.taps_y * p.taps_x * p.x_C;
+  const int z = p.split_k > 1 ? p.split_k : 1;
+  dim3 grid((unsigned)(((Cout + 127) / 128) * ((Ktot + 127) / 128)), 1, z);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
+}
+
+bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
+  if (!p || !p->x || p->x_ld <= 0 || p->x_H <= 0 || p->x_W <= 0 || p->n_img <= 0 || p->g_H <= 0 || p->g_W <= 0) return false;
+  if (p->taps_y <= 0 || p->taps_x <= 0 || p->N <= 0) return false;
+  const int cpc = p->dtype == MIREG_DTYPE_BF16 ? 8 : 4;
+  if (p->dtype != MIREG_DTYPE_BF16 && p->dtype != MIREG_DTYPE_F32) return false;
+  if (p->x_C <= 0 || p->x_C % cpc || p->x_ld % cpc || ((uintptr_t)p->x % 16)) return false;
+  if ((long)p->n_img * p->g_H * p->g_W >= (1L << 31)) return false;
+  if (wgrad) {
+    if (!p->y || !p->slab || p->y_ld % cpc || ((uintptr_t)p->y % 16)) return false;
+  } else {
+    if (!p->w || p->w_ld % cpc || ((uintptr_t)p->w % 16)) return false;
+    if (!p->y && !p->y32) return false;
+    if (p->split_k > 1 && !p->slab) return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream) {
+  if (!desc_ok(desc, false)) return MIREG_ERR_ARG;
+  return desc->dtype == MIREG_DTYPE_BF16 ? launch_fwd<__bf16>(*desc, stream) : launch_fwd<float>(*desc, stream);
+}
+
+int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream) {
+  if (!desc_ok(desc, true)) return MIREG_ERR_ARG;
+  return desc->dtype == MIREG_DTYPE_BF16 ? launch_wgrad<__bf16>(*desc, stream) : launch_wgrad<float>(*desc, stream);
+}
+
+}  // extern "C"

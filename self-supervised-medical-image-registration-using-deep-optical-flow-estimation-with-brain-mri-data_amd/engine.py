@@ -1,0 +1,331 @@
+"""Host-side engine primitives: NHWC views, conv descriptors and launch helpers over the C ABI.
+
+Everything here is plumbing (pointer arithmetic, descriptor filling, launch order); every byte of
+arithmetic happens in csrc/*.hip.  Layout rules:
+  * activations / gradients are NHWC with a pixel stride `ld` (elements), channel counts padded to 8
+    with zeros, so a producer can write into a channel slice of a concat buffer (no torch.cat);
+  * Conv2d weights [Co][Ci][kh][kw] are packed once per optimizer step into
+      FWD   pack  [Co][(ky,kx,ci_pad)]                 (forward of a conv, backward-data of a deconv)
+      DGRAD packs [Ci][(ty,tx,co_pad)] per parity class  (backward-data of a conv, forward of a deconv)
+    ConvTranspose2d weights [Cin][Cout][kh][kw] are the Conv2d weights of the adjoint conv, so a
+    deconvolution is just the same layer object used the other way round.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+DT_F32, DT_BF16 = 0, 1
+
+
+def rup(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("x_ld", ctypes.c_long), ("x_H", ctypes.c_int), ("x_W", ctypes.c_int),
+                ("x_C", ctypes.c_int), ("taps_y", ctypes.c_int), ("taps_x", ctypes.c_int),
+                ("mul_y", ctypes.c_int), ("mul_x", ctypes.c_int), ("off_y", ctypes.c_int), ("off_x", ctypes.c_int),
+                ("step_y", ctypes.c_int), ("step_x", ctypes.c_int),
+                ("g_H", ctypes.c_int), ("g_W", ctypes.c_int), ("n_img", ctypes.c_int),
+                ("w", ctypes.c_void_p), ("w_ld", ctypes.c_long), ("N", ctypes.c_int),
+                ("y", ctypes.c_void_p), ("y_ld", ctypes.c_long), ("y_H", ctypes.c_int), ("y_W", ctypes.c_int),
+                ("y_mul_y", ctypes.c_int), ("y_mul_x", ctypes.c_int), ("y_off_y", ctypes.c_int), ("y_off_x", ctypes.c_int),
+                ("y32", ctypes.c_void_p), ("y32_ld", ctypes.c_long),
+                ("bias", ctypes.c_void_p), ("slope", ctypes.c_float), ("accumulate", ctypes.c_int), ("dtype", ctypes.c_int),
+                ("split_k", ctypes.c_int), ("slab", ctypes.c_void_p)]
+
+
+class PackJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("Co", ctypes.c_int), ("Ci", ctypes.c_int),
+                ("kh", ctypes.c_int), ("kw", ctypes.c_int), ("kind", ctypes.c_int), ("Cpad", ctypes.c_int),
+                ("ky0", ctypes.c_int), ("kx0", ctypes.c_int), ("sy", ctypes.c_int), ("sx", ctypes.c_int),
+                ("nty", ctypes.c_int), ("ntx", ctypes.c_int), ("ld", ctypes.c_long), ("rows", ctypes.c_int)]
+
+
+class AdamJob(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("n", ctypes.c_long)]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def upload_table(jobs: Sequence[ctypes.Structure], device) -> torch.Tensor:
+    """Copy an array of POD job structs into a device byte tensor (kept alive by the caller)."""
+    arr = (type(jobs[0]) * len(jobs))(*jobs)
+    raw = bytes(memoryview(arr).cast("B"))
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+@dataclass
+class View:
+    """A channel slice [c0, c0+C) of an NHWC buffer of shape (B, H, W, ld)."""
+    buf: torch.Tensor
+    B: int
+    H: int
+    W: int
+    C: int
+    c0: int = 0
+
+    @property
+    def ld(self) -> int:
+        return self.buf.shape[-1]
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + self.c0 * self.buf.element_size()
+
+    @property
+    def rows(self) -> int:
+        return self.B * self.H * self.W
+
+    def slice(self, c0: int, C: int) -> "View":
+        assert c0 >= 0 and self.c0 + c0 + C <= self.ld
+        return View(self.buf, self.B, self.H, self.W, C, self.c0 + c0)
+
+    def nchw(self) -> torch.Tensor:
+        """Logical (B, C, H, W) tensor aliasing this view (channels_last-style strides)."""
+        return self.buf.view(self.B, self.H, self.W, self.ld)[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2)
+
+
+class Workspace:
+    """Owns NHWC buffers (zero-initialised so pad channels stay zero forever) and scratch slabs."""
+
+    def __init__(self, device, dtype: torch.dtype):
+        self.device, self.dtype = device, dtype
+        self.code = DT_BF16 if dtype == torch.bfloat16 else DT_F32
+        self.scratch: Optional[torch.Tensor] = None
+        self.scratch_elems = 0
+
+    def new(self, B: int, H: int, W: int, C: int, dtype: Optional[torch.dtype] = None, pad: int = 8) -> View:
+        buf = torch.zeros(B, H, W, rup(C, pad), device=self.device, dtype=dtype or self.dtype)
+        return View(buf, B, H, W, C, 0)
+
+    def need_scratch(self, elems: int) -> None:
+        self.scratch_elems = max(self.scratch_elems, elems)
+
+    def get_scratch(self) -> torch.Tensor:
+        if self.scratch is None or self.scratch.numel() < self.scratch_elems:
+            self.scratch = torch.empty(max(self.scratch_elems, 1), device=self.device, dtype=F32)
+        return self.scratch
+
+
+NUM_CU = 256
+
+
+def _split_for(tiles: int, nk: int, cap: int = 32) -> int:
+    if tiles >= NUM_CU or nk < 8:
+        return 1
+    return max(1, min((2 * NUM_CU + tiles - 1) // tiles, nk // 4, cap))
+
+
+class ConvLayer:
+    """One Conv2d-shaped weight W[Co][Ci][kh][kw] (stride s, padding p, dilation d) and its packs.
+
+    used as a convolution      : fwd = FWD form,  bwd-data = DGRAD form, bwd-weights = WGRAD(x, dy)
+    used as a deconvolution    : fwd = DGRAD form, bwd-data = FWD form,  bwd-weights = WGRAD(dy, x)
+    (ConvTranspose2d(Cin, Cout) weights are [Cin][Cout][kh][kw] == this class with Co=Cin, Ci=Cout.)
+    """
+
+    def __init__(self, name: str, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, pad: int, dil: int,
+                 ws: Workspace):
+        self.name, self.weight, self.bias = name, weight, bias
+        self.Co, self.Ci, self.kh, self.kw = weight.shape
+        self.s, self.p, self.d = stride, pad, dil
+        self.ws = ws
+        self.Cip, self.Cop = rup(self.Ci, 8), rup(self.Co, 8)
+        dev, dt = ws.device, ws.dtype
+        self.Kf = self.kh * self.kw * self.Cip
+        self.packF = torch.zeros(self.Co, self.Kf, device=dev, dtype=dt)
+        # DGRAD packs, one per parity class of the (larger) image
+        self.classes = []
+        for py in range(self.s):
+            for px in range(self.s):
+                ky0, kx0 = (py + self.p) % self.s, (px + self.p) % self.s
+                nty = (self.kh - ky0 + self.s - 1) // self.s if self.kh > ky0 else 0
+                ntx = (self.kw - kx0 + self.s - 1) // self.s if self.kw > kx0 else 0
+                cy, cx = (py + self.p - ky0) // self.s, (px + self.p - kx0) // self.s
+                K = nty * ntx * self.Cop
+                pack = torch.zeros(self.Ci, max(K, 8), device=dev, dtype=dt)
+                self.classes.append(dict(py=py, px=px, ky0=ky0, kx0=kx0, nty=nty, ntx=ntx, cy=cy, cx=cx, K=K, pack=pack))
+        self.wgrad_slab: Optional[torch.Tensor] = None
+        self.wgrad_split = 1
+        self.grad_w: Optional[torch.Tensor] = None
+        self.grad_b: Optional[torch.Tensor] = None
+
+    # ---- pack jobs ----------------------------------------------------------------------------
+    def pack_jobs(self) -> List[PackJob]:
+        jobs = [PackJob(self.weight.data_ptr(), self.packF.data_ptr(), self.Co, self.Ci, self.kh, self.kw, 0, self.Cip,
+                        0, 0, 1, 1, self.kh, self.kw, self.Kf, self.Co)]
+        for c in self.classes:
+            if c["K"] == 0:
+                continue
+            jobs.append(PackJob(self.weight.data_ptr(), c["pack"].data_ptr(), self.Co, self.Ci, self.kh, self.kw, 1,
+                                self.Cop, c["ky0"], c["kx0"], self.s, self.s, c["nty"], c["ntx"], c["pack"].shape[1],
+                                self.Ci))
+        return jobs
+
+    def unpack_job(self, accumulate: bool = False) -> PackJob:
+        assert self.wgrad_slab is not None and self.grad_w is not None
+        return PackJob(self.wgrad_slab.data_ptr(), self.grad_w.data_ptr(), self.Co, self.Ci, self.kh, self.kw,
+                       int(accumulate), self.Cip, 0, 0, self.wgrad_split, 1, self.kh, self.kw, self.Kf, self.Co)
+
+    # ---- launches -----------------------------------------------------------------------------
+    def _finish(self, d: ConvDesc, M: int, N: int, K: int, allow_split: bool) -> None:
+        bk = 32 if self.ws.code == DT_BF16 else 16
+        bn = 128 if N > 64 else (64 if N > 32 else 32)
+        tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
+        nk = (K + bk - 1) // bk
+        split = _split_for(tiles, nk) if allow_split else 1
+        d.split_k = split
+        if split > 1:
+            self.ws.need_scratch(split * M * N)
+            d.slab = self.ws.get_scratch().data_ptr()
+        d.dtype = self.ws.code
+
+    def run_fwd_form(self, x: View, y: Optional[View], *, y32: Optional[View] = None, slope: float = 1.0,
+                     bias: bool = True, accumulate: bool = False) -> None:
+        """y[(oy,ox)] = act(sum_{ky,kx,ci} x[oy*s-p+ky*d, ox*s-p+kx*d, ci] W[co][ci][ky][kx] + b)."""
+        assert x.C <= self.Cip and x.c0 + self.Cip <= x.ld, (self.name, x.C, self.Ci, x.ld)
+        Ho = (x.H + 2 * self.p - self.d * (self.kh - 1) - 1) // self.s + 1
+        Wo = (x.W + 2 * self.p - self.d * (self.kw - 1) - 1) // self.s + 1
+        out = y if y is not None else y32
+        assert (out.H, out.W) == (Ho, Wo), (self.name, (out.H, out.W), (Ho, Wo))
+        d = ConvDesc()
+        d.x, d.x_ld, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, x.H, x.W, self.Cip
+        d.taps_y, d.taps_x = self.kh, self.kw
+        d.mul_y = d.mul_x = self.s
+        d.off_y = d.off_x = -self.p
+        d.step_y = d.step_x = self.d
+        d.g_H, d.g_W, d.n_img = Ho, Wo, x.B
+        d.w, d.w_ld, d.N = self.packF.data_ptr(), self.Kf, self.Co
+        self._fill_out(d, y, y32, Ho, Wo, 1, 1, 0, 0)
+        d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
+        d.slope, d.accumulate = slope, int(accumulate)
+        self._finish(d, x.B * Ho * Wo, self.Co, self.Kf, True)
+        _lib.call("mireg_conv_gemm", ctypes.byref(d), _stream())
+
+    @staticmethod
+    def _fill_out(d, y, y32, yH, yW, mul_y, mul_x, off_y, off_x):
+        if y is not None:
+            d.y, d.y_ld = y.ptr, y.ld
+        if y32 is not None:
+            d.y32, d.y32_ld = y32.ptr, y32.ld
+        d.y_H, d.y_W, d.y_mul_y, d.y_mul_x, d.y_off_y, d.y_off_x = yH, yW, mul_y, mul_x, off_y, off_x
+
+    def run_dgrad_form(self, g: View, out: Optional[View], *, y32: Optional[View] = None, slope: float = 1.0,
+                       bias: bool = False, accumulate: bool = False) -> None:
+        """out[(iy,ix), ci] = act(sum_{ky,kx,co} g[(iy+p-ky*d)/s, (ix+p-kx*d)/s, co] W[co][ci][ky][kx] + b[ci])
+        (only exact divisions contribute).  out has the LARGER spatial size."""
+        assert g.C <= self.Cop and g.c0 + self.Cop <= g.ld, (self.name, g.C, self.Co, g.ld)
+        o = out if out is not None else y32
+        for c in self.classes:
+            gH = (o.H - c["py"] + self.s - 1) // self.s
+            gW = (o.W - c["px"] + self.s - 1) // self.s
+            if gH <= 0 or gW <= 0:
+                continue
+            assert c["K"] > 0, "kernel smaller than stride is not supported"
+            d = ConvDesc()
+            d.x, d.x_ld, d.x_H, d.x_W, d.x_C = g.ptr, g.ld, g.H, g.W, self.Cop
+            d.taps_y, d.taps_x = c["nty"], c["ntx"]
+            d.mul_y = d.mul_x = 1
+            if self.s == 1:
+                d.off_y = d.off_x = self.p
+                d.step_y = d.step_x = -self.d
+            else:
+                d.off_y, d.off_x = c["cy"], c["cx"]
+                d.step_y = d.step_x = -1
+            d.g_H, d.g_W, d.n_img = gH, gW, g.B
+            d.w, d.w_ld, d.N = c["pack"].data_ptr(), c["pack"].shape[1], self.Ci
+            self._fill_out(d, out, y32, o.H, o.W, self.s, self.s, c["py"], c["px"])
+            d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
+            d.slope, d.accumulate = slope, int(accumulate)
+            self._finish(d, g.B * gH * gW, self.Ci, c["K"], True)
+            _lib.call("mireg_conv_gemm", ctypes.byref(d), _stream())
+
+    def plan_wgrad(self, x: View, dy: View) -> None:
+        """Size the persistent split-K slab for dW[co][(ky,kx,ci_pad)] = sum_pix dy[pix][co] x[pix@tap][ci]."""
+        bk = 32 if self.ws.code == DT_BF16 else 16
+        tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
+        nk = (dy.rows + bk - 1) // bk
+        self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((2 * NUM_CU + tiles - 1) // tiles, max(nk // 2, 1), 128))
+        self.wgrad_slab = torch.empty(self.wgrad_split, self.Co, self.Kf, device=self.ws.device, dtype=F32)
+        self.grad_w = torch.zeros_like(self.weight, dtype=F32)
+        if self.bias is not None:
+            self.grad_b = torch.zeros_like(self.bias, dtype=F32)
+
+    def run_wgrad(self, x: View, dy: View) -> None:
+        """x: tensor in this conv's INPUT space (C = Ci), dy: tensor in its OUTPUT space (C = Co)."""
+        if self.wgrad_slab is None:
+            self.plan_wgrad(x, dy)
+        assert x.C <= self.Cip and x.c0 + self.Cip <= x.ld and dy.c0 + rup(self.Co, 8) <= dy.ld, self.name
+        d = ConvDesc()
+        d.x, d.x_ld, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, x.H, x.W, self.Cip
+        d.taps_y, d.taps_x = self.kh, self.kw
+        d.mul_y = d.mul_x = self.s
+        d.off_y = d.off_x = -self.p
+        d.step_y = d.step_x = self.d
+        d.g_H, d.g_W, d.n_img = dy.H, dy.W, dy.B
+        d.y, d.y_ld, d.N = dy.ptr, dy.ld, self.Co
+        d.split_k, d.slab, d.dtype = self.wgrad_split, self.wgrad_slab.data_ptr(), self.ws.code
+        _lib.call("mireg_conv_wgrad", ctypes.byref(d), _stream())
+
+    def run_bias_grad(self, dy: View, accumulate: bool = False) -> None:
+        if self.bias is None:
+            return
+        _lib.call("mireg_colsum", dy.ptr, dy.ld, dy.rows, dy.C, self.grad_b.data_ptr(), int(accumulate), self.ws.code,
+                  _stream())
+
+
+class BatchNormAct:
+    """Train/eval BatchNorm2d + LeakyReLU on an NHWC view (reference FlowNetS/util.py:17-30)."""
+
+    def __init__(self, bn: torch.nn.BatchNorm2d, ws: Workspace, slope: float = 0.1):
+        self.bn, self.ws, self.slope = bn, ws, slope
+        C = bn.num_features
+        self.C = C
+        self.sums = torch.zeros(2 * C, device=ws.device, dtype=torch.float64)
+        self.ss = torch.zeros(4 * C, device=ws.device, dtype=F32)
+        self.grad_g = torch.zeros(C, device=ws.device, dtype=F32)
+        self.grad_b = torch.zeros(C, device=ws.device, dtype=F32)
+
+    def forward(self, y: View, out: View, training: bool) -> None:
+        st = _stream()
+        bn = self.bn
+        if training:
+            _lib.call("mireg_bn_stats", y.ptr, y.ld, y.rows, self.C, self.sums.data_ptr(), self.ws.code, st)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        _lib.call("mireg_bn_finalize", self.sums.data_ptr(), y.rows, self.C, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(mom), float(bn.eps), int(training),
+                  self.ss.data_ptr(), st)
+        _lib.call("mireg_bn_apply", y.ptr, y.ld, out.ptr, out.ld, self.ss.data_ptr(), y.rows, self.C, self.slope,
+                  self.ws.code, st)
+
+    def backward(self, y: View, da: View, dy: View) -> None:
+        _lib.call("mireg_bn_bwd", y.ptr, y.ld, da.ptr, da.ld, dy.ptr, dy.ld, self.ss.data_ptr(), self.sums.data_ptr(),
+                  self.grad_g.data_ptr(), self.grad_b.data_ptr(), 0, y.rows, self.C, self.slope, self.ws.code, _stream())
+
+
+def lrelu_bwd(g: View, a: View, slope: float, ws: Workspace) -> None:
+    _lib.call("mireg_lrelu_bwd", g.ptr, g.ld, a.ptr, a.ld, g.rows, g.C, slope, ws.code, _stream())
+
+
+def nchw_to_view(src: torch.Tensor, c0: int, nc: int, dst: View, code: Optional[int] = None) -> None:
+    """src (B, Ctot, H, W) fp32 contiguous, channels [c0, c0+nc) -> dst channels [0, nc)."""
+    B, Ctot, H, W = src.shape
+    if code is None:
+        code = DT_BF16 if dst.buf.dtype == torch.bfloat16 else DT_F32
+    _lib.call("mireg_nchw_to_nhwc", src.data_ptr(), dst.ptr, B, Ctot, c0, nc, H * W, dst.ld, code, _stream())
+
+
+def cast_from_f32(dst: View, src: View, alpha: float = 1.0, beta: float = 0.0) -> None:
+    code = DT_BF16 if dst.buf.dtype == torch.bfloat16 else DT_F32
+    _lib.call("mireg_cast_from_f32", dst.ptr, dst.ld, src.ptr, src.ld, dst.rows, dst.C, alpha, beta, code, _stream())

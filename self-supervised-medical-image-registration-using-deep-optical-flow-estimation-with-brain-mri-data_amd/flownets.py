@@ -1,0 +1,326 @@
+"""FlowNetS predictor (reference FlowNetS/FlowNetS.py:10-93, FlowNetS/util.py:17-55) on the HIP engine.
+
+The nn.Module keeps the reference's submodule names, constructor signature, init and train/eval
+return arity, so state_dicts interchange key for key.  Its forward/backward are two hand-scheduled
+kernel sequences over persistent NHWC buffers (no torch.cat, no ATen/MIOpen calls).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import (DT_BF16, F32, BatchNormAct, ConvLayer, View, Workspace, _stream, cast_from_f32, lrelu_bwd,
+                     nchw_to_view, upload_table)
+
+ENCODER = [  # name, cin, cout, k, stride   (FlowNetS/FlowNetS.py:17-26)
+    ("conv1", 2, 64, 7, 2), ("conv2", 64, 128, 5, 2), ("conv3", 128, 256, 5, 2), ("conv3_1", 256, 256, 3, 1),
+    ("conv4", 256, 512, 3, 2), ("conv4_1", 512, 512, 3, 1), ("conv5", 512, 512, 3, 2), ("conv5_1", 512, 512, 3, 1),
+    ("conv6", 512, 1024, 3, 2), ("conv6_1", 1024, 1024, 3, 1)]
+DECONV = {5: (1024, 512), 4: (1026, 256), 3: (770, 128), 2: (386, 64)}   # FlowNetS.py:28-31
+PREDICT = {6: 1024, 5: 1026, 4: 770, 3: 386, 2: 194}                      # FlowNetS.py:33-37
+SLOPE = 0.1
+
+
+def conv_block(bn: bool, cin: int, cout: int, k: int = 3, stride: int = 1) -> nn.Sequential:
+    layers: List[nn.Module] = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=not bn)]
+    if bn:
+        layers.append(nn.BatchNorm2d(cout))
+    layers.append(nn.LeakyReLU(SLOPE, inplace=True))
+    return nn.Sequential(*layers)
+
+
+class PredictorEngineBase:
+    """Shared by the predictors: weight packing, gradient unpacking, parameter <-> grad bookkeeping."""
+
+    def __init__(self, module: nn.Module, B: int, H: int, W: int, device, dtype: torch.dtype):
+        self.module, self.B, self.H, self.W = module, B, H, W
+        self.ws = Workspace(device, dtype)
+        self.layers: Dict[str, ConvLayer] = {}
+        self.bns: Dict[str, BatchNormAct] = {}
+        self._pack_table = None
+        self._pack_key = None
+        self._unpack_table = None
+        self.training_cache = False
+
+    # -- parameters ---------------------------------------------------------------------------------
+    def add_conv(self, name: str, conv: nn.Module, stride: int, pad: int, dil: int = 1) -> ConvLayer:
+        lay = ConvLayer(name, conv.weight, conv.bias, stride, pad, dil, self.ws)
+        self.layers[name] = lay
+        return lay
+
+    def pack_weights(self) -> None:
+        """torch-layout fp32 parameters -> GEMM packs (one table-driven launch)."""
+        key = tuple(l.weight.data_ptr() for l in self.layers.values())
+        if self._pack_key != key:
+            jobs = [j for l in self.layers.values() for j in l.pack_jobs()]
+            self._pack_table, self._pack_n, self._pack_key = upload_table(jobs, self.ws.device), len(jobs), key
+        _lib.call("mireg_pack_weights", self._pack_table.data_ptr(), self._pack_n, self.ws.code, _stream())
+
+    def unpack_grads(self) -> None:
+        if self._unpack_table is None:
+            jobs = [l.unpack_job() for l in self.layers.values() if l.wgrad_slab is not None]
+            self._unpack_table, self._unpack_n = upload_table(jobs, self.ws.device), len(jobs)
+        _lib.call("mireg_unpack_wgrad", self._unpack_table.data_ptr(), self._unpack_n, _stream())
+
+    def param_grads(self) -> Dict[int, torch.Tensor]:
+        """id(parameter) -> persistent fp32 gradient buffer (torch layout)."""
+        out = {}
+        for l in self.layers.values():
+            if l.grad_w is not None:
+                out[id(l.weight)] = l.grad_w
+            if l.bias is not None and l.grad_b is not None:
+                out[id(l.bias)] = l.grad_b
+        for b in self.bns.values():
+            out[id(b.bn.weight)] = b.grad_g
+            out[id(b.bn.bias)] = b.grad_b
+        return out
+
+
+class FlowNetSEngine(PredictorEngineBase):
+    def __init__(self, module: "FlowNetS", B: int, H: int, W: int, device, dtype: torch.dtype):
+        super().__init__(module, B, H, W, device, dtype)
+        if H % 64 or W % 64:
+            raise RuntimeError(f"FlowNetS engine needs H, W divisible by 64, got {H}x{W}")
+        ws, m = self.ws, module
+        self.bn = m.batchNorm
+        for name, cin, cout, k, s in ENCODER:
+            seq = getattr(m, name)
+            self.add_conv(name, seq[0], s, (k - 1) // 2)
+            if self.bn:
+                self.bns[name] = BatchNormAct(seq[1], ws, SLOPE)
+        for lvl in DECONV:
+            self.add_conv(f"deconv{lvl}", getattr(m, f"deconv{lvl}")[0], 2, 1)        # adjoint conv: Co=cin_deconv
+        for lvl in PREDICT:
+            self.add_conv(f"predict_flow{lvl}", getattr(m, f"predict_flow{lvl}"), 1, 1)
+        for lvl in (6, 5, 4, 3):
+            self.add_conv(f"up{lvl}", getattr(m, f"upsampled_flow{lvl}_to_{lvl - 1}"), 2, 1)
+        # ---- buffers -----------------------------------------------------------------------------
+        hs = {lvl: (H >> lvl, W >> lvl) for lvl in range(1, 7)}
+        self.hs = hs
+        new = ws.new
+        self.x8 = new(B, H, W, 2)
+        self.a1 = new(B, *hs[1], 64)
+        self.cat = {2: new(B, *hs[2], 194), 3: new(B, *hs[3], 386), 4: new(B, *hs[4], 770), 5: new(B, *hs[5], 1026)}
+        self.skip_c = {2: 128, 3: 256, 4: 512, 5: 512}
+        self.a3, self.a4, self.a5 = new(B, *hs[3], 256), new(B, *hs[4], 512), new(B, *hs[5], 512)
+        self.a6, self.a61 = new(B, *hs[6], 1024), new(B, *hs[6], 1024)
+        enc_out = {"conv1": (1, 64), "conv2": (2, 128), "conv3": (3, 256), "conv3_1": (3, 256), "conv4": (4, 512),
+                   "conv4_1": (4, 512), "conv5": (5, 512), "conv5_1": (5, 512), "conv6": (6, 1024), "conv6_1": (6, 1024)}
+        self.raw = {n: new(B, *hs[l], c) for n, (l, c) in enc_out.items()} if self.bn else {}
+        self.flow32 = {lvl: new(B, *hs[lvl], 2, dtype=F32, pad=2) for lvl in PREDICT}
+        self.flowT = {lvl: new(B, *hs[lvl], 2) for lvl in PREDICT}
+        self.flow0 = new(B, 256, 256, 2, dtype=F32, pad=2)
+        # where each encoder conv reads / writes
+        c = self.cat
+        self.enc_io = {
+            "conv1": (self.x8, self.a1), "conv2": (self.a1, c[2].slice(0, 128)), "conv3": (c[2].slice(0, 128), self.a3),
+            "conv3_1": (self.a3, c[3].slice(0, 256)), "conv4": (c[3].slice(0, 256), self.a4),
+            "conv4_1": (self.a4, c[4].slice(0, 512)), "conv5": (c[4].slice(0, 512), self.a5),
+            "conv5_1": (self.a5, c[5].slice(0, 512)), "conv6": (c[5].slice(0, 512), self.a6), "conv6_1": (self.a6, self.a61)}
+        self.grads_ready = False
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, training: bool) -> List[torch.Tensor]:
+        L, c = self.layers, self.cat
+        self.training_cache = training
+        self.pack_weights()
+        x = x.contiguous()
+        nchw_to_view(x, 0, 2, self.x8)
+        for name, *_ in ENCODER:
+            src, dst = self.enc_io[name]
+            if self.bn:
+                L[name].run_fwd_form(src, self.raw[name])
+                self.bns[name].forward(self.raw[name], dst, training)
+            else:
+                L[name].run_fwd_form(src, dst, slope=SLOPE)
+        feat = self.a61
+        L["predict_flow6"].run_fwd_form(feat, self.flowT[6], y32=self.flow32[6])
+        for lvl in (5, 4, 3, 2):
+            cs = self.skip_c[lvl]
+            cd = DECONV[lvl][1]
+            L[f"up{lvl + 1}"].run_dgrad_form(self.flowT[lvl + 1], c[lvl].slice(cs + cd, 2), bias=True)
+            L[f"deconv{lvl}"].run_dgrad_form(feat, c[lvl].slice(cs, cd), slope=SLOPE, bias=True)
+            feat = c[lvl]
+            L[f"predict_flow{lvl}"].run_fwd_form(feat, self.flowT[lvl], y32=self.flow32[lvl])
+        f2 = self.flow32[2]
+        _lib.call("mireg_resize_bilinear_fwd", f2.ptr, self.flow0.ptr, self.B, 2, f2.H, f2.W, 256, 256,
+                  f2.H * f2.W * 2, 1, 2, 256 * 256 * 2, 1, 2, 0, _stream())
+        flows = [self.flow0.nchw(), f2.nchw()]
+        if training:
+            flows += [self.flow32[l].nchw() for l in (3, 4, 5, 6)]
+        return flows
+
+    # ------------------------------------------------------------------------------------------------
+    def _ensure_grad_buffers(self) -> None:
+        if self.grads_ready:
+            return
+        ws, new, hs, B = self.ws, self.ws.new, self.hs, self.B
+        self.dcat = {lvl: new(B, *hs[lvl], v.C) for lvl, v in self.cat.items()}
+        self.da1, self.da3, self.da4 = new(B, *hs[1], 64), new(B, *hs[3], 256), new(B, *hs[4], 512)
+        self.da5, self.da6, self.da61 = new(B, *hs[5], 512), new(B, *hs[6], 1024), new(B, *hs[6], 1024)
+        self.draw = {n: new(B, v.H, v.W, v.C) for n, v in self.raw.items()}
+        self.dflowT = {lvl: new(B, *hs[lvl], 2) for lvl in PREDICT}
+        self.dflow32 = new(B, *hs[2], 2, dtype=F32, pad=2)
+        self.gtmp = {lvl: torch.zeros(B, 2, *hs[lvl], device=ws.device, dtype=F32) for lvl in PREDICT}
+        c, dc = self.cat, self.dcat
+        self.enc_dio = {  # (grad wrt conv input, accumulate?), grad wrt conv output (activated)
+            "conv1": (None, False, self.da1), "conv2": (self.da1, False, dc[2].slice(0, 128)),
+            "conv3": (dc[2].slice(0, 128), True, self.da3), "conv3_1": (self.da3, False, dc[3].slice(0, 256)),
+            "conv4": (dc[3].slice(0, 256), True, self.da4), "conv4_1": (self.da4, False, dc[4].slice(0, 512)),
+            "conv5": (dc[4].slice(0, 512), True, self.da5), "conv5_1": (self.da5, False, dc[5].slice(0, 512)),
+            "conv6": (dc[5].slice(0, 512), True, self.da6), "conv6_1": (self.da6, False, self.da61)}
+        self.grads_ready = True
+
+    def backward(self, gflows: Sequence[Optional[torch.Tensor]]) -> None:
+        """gflows: gradients wrt (flow0, flow2, flow3, flow4, flow5, flow6) as (B,2,h,w) fp32 or None."""
+        self._ensure_grad_buffers()
+        L, c, dc, B, st = self.layers, self.cat, self.dcat, self.B, _stream()
+        g = list(gflows) + [None] * (6 - len(gflows))
+        glvl = {2: g[1], 3: g[2], 4: g[3], 5: g[4], 6: g[5]}
+
+        def load_loss_grad(lvl: int) -> None:
+            """dflowT[lvl] <- loss gradient (zero if the flow was unused)."""
+            gt = glvl[lvl]
+            dst = self.dflowT[lvl]
+            if lvl == 2:
+                d32 = self.dflow32
+                if gt is None:
+                    d32.buf.zero_()
+                else:
+                    nchw_to_view(gt.contiguous(), 0, 2, d32)
+                if g[0] is not None:
+                    g0 = g[0].contiguous()
+                    _lib.call("mireg_resize_bilinear_bwd", g0.data_ptr(), d32.ptr, B, 2, d32.H, d32.W, 256, 256,
+                              d32.H * d32.W * 2, 1, 2, 2 * 256 * 256, 256 * 256, 1, 0, 1.0, st)
+                cast_from_f32(dst, d32)
+            elif gt is None:
+                dst.buf.zero_()
+            else:
+                nchw_to_view(gt.contiguous(), 0, 2, dst)
+
+        # ---- decoder, fine -> coarse ---------------------------------------------------------------
+        load_loss_grad(2)
+        pf = L["predict_flow2"]
+        pf.run_wgrad(c[2], self.dflowT[2])
+        pf.run_bias_grad(self.dflowT[2])
+        pf.run_dgrad_form(self.dflowT[2], dc[2])                              # dcat2 <- (beta 0)
+        for lvl in (2, 3, 4, 5):
+            # dcat[lvl] holds every decoder-side contribution now; push it one level coarser
+            cs, cd = self.skip_c[lvl], DECONV[lvl][1]
+            feat_prev, dfeat_prev = (c[lvl + 1], dc[lvl + 1]) if lvl < 5 else (self.a61, self.da61)
+            # flow upsampler (lvl+1 -> lvl): no activation
+            gup = dc[lvl].slice(cs + cd, 2)
+            up = L[f"up{lvl + 1}"]
+            load_loss_grad(lvl + 1)                                           # dflowT[lvl+1] <- loss grad
+            up.run_wgrad(gup, self.flowT[lvl + 1])
+            up.run_bias_grad(gup)
+            up.run_fwd_form(gup, self.dflowT[lvl + 1], bias=False, accumulate=True)
+            # feature deconv (lvl+1 -> lvl) + LeakyReLU
+            gde = dc[lvl].slice(cs, cd)
+            lrelu_bwd(gde, c[lvl].slice(cs, cd), SLOPE, self.ws)
+            de = L[f"deconv{lvl}"]
+            de.run_wgrad(gde, feat_prev)
+            de.run_bias_grad(gde)
+            # predict_flow{lvl+1} writes dfeat_prev first (beta 0), the deconv then accumulates into it
+            pfn = L[f"predict_flow{lvl + 1}"]
+            pfn.run_wgrad(feat_prev, self.dflowT[lvl + 1])
+            pfn.run_bias_grad(self.dflowT[lvl + 1])
+            pfn.run_dgrad_form(self.dflowT[lvl + 1], dfeat_prev)
+            de.run_fwd_form(gde, dfeat_prev, bias=False, accumulate=True)
+        # ---- encoder, coarse -> fine ---------------------------------------------------------------
+        for name, *_ in reversed(ENCODER):
+            src, dst = self.enc_io[name]
+            dsrc, acc, ddst = self.enc_dio[name]
+            lay = L[name]
+            if self.bn:
+                self.bns[name].backward(self.raw[name], ddst, self.draw[name])
+                dy = self.draw[name]
+            else:
+                lrelu_bwd(ddst, dst, SLOPE, self.ws)
+                dy = ddst
+                lay.run_bias_grad(dy)
+            lay.run_wgrad(src, dy)
+            if dsrc is not None:
+                lay.run_dgrad_form(dy, dsrc, accumulate=acc)
+        self.unpack_grads()
+
+
+class _FlowNetSFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        eng = module.engine_for(x)
+        flows = eng.forward(x, module.training)
+        ctx.eng, ctx.module = eng, module
+        return tuple(flows)
+
+    @staticmethod
+    def backward(ctx, *gflows):
+        eng = ctx.eng
+        if eng.training_cache:
+            g = gflows
+        else:  # eval arity (flow0, flow2)
+            g = (gflows[0], gflows[1], None, None, None, None)
+        eng.backward(g)
+        table = eng.param_grads()
+        grads = tuple(table[id(p)].clone() if id(p) in table else None for p in ctx.module.parameters())
+        return (None, None) + grads
+
+
+class FlowNetS(nn.Module):
+    """Drop-in for reference FlowNetS.FlowNetS.FlowNetS (constructor `batchNorm=True`).
+
+    precision: "bf16" (bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the throughput
+    mode BASELINE.json names) or "fp32" (exact-fp32 MFMA, the parity mode)."""
+    expansion = 1
+
+    def __init__(self, batchNorm: bool = True, precision: str = "bf16"):
+        super().__init__()
+        self.batchNorm = batchNorm
+        self.precision = precision
+        for name, cin, cout, k, s in ENCODER:
+            setattr(self, name, conv_block(batchNorm, cin, cout, k, s))
+        for lvl, (cin, cout) in DECONV.items():
+            setattr(self, f"deconv{lvl}", nn.Sequential(nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=False),
+                                                       nn.LeakyReLU(SLOPE, inplace=True)))
+        for lvl, cin in PREDICT.items():
+            setattr(self, f"predict_flow{lvl}", nn.Conv2d(cin, 2, 3, 1, 1, bias=False))
+        for lvl in (6, 5, 4, 3):
+            setattr(self, f"upsampled_flow{lvl}_to_{lvl - 1}", nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=False))
+        for m in self.modules():  # FlowNetS/FlowNetS.py:44-51 (second positional of kaiming_normal_ is a=0.1)
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight, 0.1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._engines: Dict[tuple, FlowNetSEngine] = {}
+
+    def engine_for(self, x: torch.Tensor) -> FlowNetSEngine:
+        if not x.is_cuda:
+            raise RuntimeError("mireg.FlowNetS runs on the MI355X only; there is no CPU fallback")
+        dtype = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        p0 = next(self.parameters())
+        if p0.device != x.device:
+            raise RuntimeError("model and input are on different devices")
+        key = (tuple(x.shape), x.device, dtype, p0.data_ptr())
+        if key not in self._engines:
+            self._engines.clear()
+            B, C, H, W = x.shape
+            if C != 2:
+                raise RuntimeError(f"FlowNetS expects (B,2,H,W) [fixed, moving], got {tuple(x.shape)}")
+            self._engines[key] = FlowNetSEngine(self, B, H, W, x.device, dtype)
+        return self._engines[key]
+
+    def forward(self, x):
+        flows = _FlowNetSFn.apply(self, x.float(), *self.parameters())
+        return tuple(flows)
+
+    def weight_parameters(self):
+        return [p for n, p in self.named_parameters() if "weight" in n]
+
+    def bias_parameters(self):
+        return [p for n, p in self.named_parameters() if "bias" in n]

@@ -1,0 +1,226 @@
+"""GPU parity of the MFMA convolution family (K1-K4) and of the FlowNetS predictor built on it.
+
+fp32 mode uses v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain): tolerance 2e-5 relative to the
+output scale per layer, flows of the whole net 1e-4 (north_star "flow L2 vs reference < 1e-4").
+bf16 mode (bf16 operands, fp32 accumulate): 2e-2 relative per layer.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _view_from(x, ws, pad_to=8):
+    from mireg.engine import View
+    B, C, H, W = x.shape
+    v = ws.new(B, H, W, C)
+    v.buf[..., :C] = x.permute(0, 2, 3, 1).to(v.buf.dtype)
+    return v
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+CASES = [  # cin, cout, k, stride, pad, dil, H, W, B, bias
+    (8, 64, 7, 2, 3, 1, 64, 64, 2, False),
+    (64, 128, 5, 2, 2, 1, 32, 32, 2, False),
+    (194, 2, 3, 1, 1, 1, 16, 16, 3, True),
+    (1026, 256, 3, 1, 1, 1, 8, 8, 2, False),
+    (128, 96, 3, 1, 8, 8, 24, 20, 1, True),     # dilated (PWC dc_conv4)
+    (256, 32, 1, 1, 0, 1, 16, 16, 2, True),     # conv_redir 1x1
+    (512, 1024, 3, 2, 1, 1, 8, 8, 3, False),    # split-K path
+    (16, 16, 3, 2, 1, 1, 30, 26, 2, True),      # odd sizes, stride 2
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_three_forms(case, prec):
+    from mireg.engine import ConvLayer, Workspace
+    cin, cout, k, s, p, d, H, W, B, has_bias = case
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    tol = 3e-5 if prec == "fp32" else 3e-2
+    ws = Workspace(torch.device(DEV), dt)
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) if has_bias else None
+    if prec == "bf16":  # compare against the same rounded operands
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y_ref = F.conv2d(xr, wr, b, s, p, d)
+    cot = torch.randn(y_ref.shape, generator=g)
+    if prec == "bf16":
+        cot = cot.bfloat16().float()
+    (y_ref * cot).sum().backward()
+    lay = ConvLayer("t", w.to(DEV), b.to(DEV) if has_bias else None, s, p, d, ws)
+    import ctypes
+    from mireg import _lib
+    from mireg.engine import upload_table, _stream
+    jobs = lay.pack_jobs()
+    tab = upload_table(jobs, DEV)
+    _lib.call("mireg_pack_weights", tab.data_ptr(), len(jobs), ws.code, _stream())
+    xv = _view_from(x.to(DEV), ws)
+    Ho, Wo = y_ref.shape[2:]
+    yv = ws.new(B, Ho, Wo, cout)
+    lay.run_fwd_form(xv, yv)
+    assert _rel(yv.nchw().float(), y_ref.detach()) < tol, "fwd"
+    # backward-data
+    gv = _view_from(cot.to(DEV), ws)
+    dxv = ws.new(B, H, W, cin)
+    lay.run_dgrad_form(gv, dxv)
+    assert _rel(dxv.nchw().float(), xr.grad) < tol, "dgrad"
+    lay.run_dgrad_form(gv, dxv, accumulate=True)
+    assert _rel(dxv.nchw().float(), 2 * xr.grad) < tol * 2, "dgrad accumulate"
+    # backward-weights
+    lay.run_wgrad(xv, gv)
+    utab = upload_table([lay.unpack_job()], DEV)
+    _lib.call("mireg_unpack_wgrad", utab.data_ptr(), 1, _stream())
+    assert _rel(lay.grad_w, wr.grad) < tol, "wgrad"
+    if has_bias:
+        lay.run_bias_grad(gv)
+        assert _rel(lay.grad_b, cot.sum((0, 2, 3))) < tol, "bias grad"
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_deconv_forms(prec):
+    """ConvTranspose2d(k4,s2,p1) == adjoint conv used backwards (FlowNetS/util.py:49-55)."""
+    from mireg.engine import ConvLayer, Workspace, upload_table, _stream
+    from mireg import _lib
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    tol = 3e-5 if prec == "fp32" else 3e-2
+    ws = Workspace(torch.device(DEV), dt)
+    g = torch.Generator().manual_seed(5)
+    for cin, cout, H, B in ((386, 64, 8, 2), (2, 2, 4, 3), (1026, 256, 4, 2)):
+        x = torch.randn(B, cin, H, H, generator=g)
+        w = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
+        bias = torch.randn(cout, generator=g)
+        if prec == "bf16":
+            x, w = x.bfloat16().float(), w.bfloat16().float()
+        xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+        y_ref = F.leaky_relu(F.conv_transpose2d(xr, wr, bias, 2, 1), 0.1)
+        cot = torch.randn(y_ref.shape, generator=g)
+        if prec == "bf16":
+            cot = cot.bfloat16().float()
+        (y_ref * cot).sum().backward()
+        lay = ConvLayer("d", w.to(DEV), bias.to(DEV), 2, 1, 1, ws)
+        jobs = lay.pack_jobs()
+        tab = upload_table(jobs, DEV)
+        _lib.call("mireg_pack_weights", tab.data_ptr(), len(jobs), ws.code, _stream())
+        xv = _view_from(x.to(DEV), ws)
+        yv = ws.new(B, 2 * H, 2 * H, cout)
+        lay.run_dgrad_form(xv, yv, slope=0.1, bias=True)
+        assert _rel(yv.nchw().float(), y_ref.detach()) < tol, "deconv fwd"
+        dz = cot * torch.where(y_ref.detach() > 0, 1.0, 0.1)
+        if prec == "bf16":
+            dz = dz.bfloat16().float()
+        gv = _view_from(dz.to(DEV), ws)
+        dxv = ws.new(B, H, H, cin)
+        lay.run_fwd_form(gv, dxv, bias=False)
+        assert _rel(dxv.nchw().float(), xr.grad) < 2 * tol, "deconv bwd-data"
+        lay.run_wgrad(gv, xv)
+        utab = upload_table([lay.unpack_job()], DEV)
+        _lib.call("mireg_unpack_wgrad", utab.data_ptr(), 1, _stream())
+        assert _rel(lay.grad_w, wr.grad) < 2 * tol, "deconv wgrad"
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_batchnorm_lrelu(prec):
+    from mireg.engine import BatchNormAct, Workspace
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    tol = 2e-5 if prec == "fp32" else 2e-2
+    ws = Workspace(torch.device(DEV), dt)
+    g = torch.Generator().manual_seed(3)
+    for C, H, B in ((64, 16, 3), (1024, 2, 2), (36, 5, 2)):
+        y = torch.randn(B, C, H, H, generator=g) * 2 + 0.5
+        if prec == "bf16":
+            y = y.bfloat16().float()
+        bn = torch.nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+            bn.bias.copy_(0.1 * torch.randn(C, generator=g))
+        bn_d = torch.nn.BatchNorm2d(C).to(DEV)
+        bn_d.load_state_dict(bn.state_dict())
+        yr = y.clone().requires_grad_()
+        out_ref = F.leaky_relu(bn(yr), 0.1)
+        cot = torch.randn(out_ref.shape, generator=g)
+        if prec == "bf16":
+            cot = cot.bfloat16().float()
+        (out_ref * cot).sum().backward()
+        op = BatchNormAct(bn_d, ws)
+        yv, ov = _view_from(y.to(DEV), ws), ws.new(B, H, H, C)
+        op.forward(yv, ov, True)
+        assert _rel(ov.nchw().float(), out_ref.detach()) < tol
+        assert _rel(bn_d.running_mean, bn.running_mean) < 1e-5 and _rel(bn_d.running_var, bn.running_var) < 1e-5
+        dav, dyv = _view_from(cot.to(DEV), ws), ws.new(B, H, H, C)
+        op.backward(yv, dav, dyv)
+        assert _rel(dyv.nchw().float(), yr.grad) < 5 * tol
+        assert _rel(op.grad_g, bn.weight.grad) < 5 * tol and _rel(op.grad_b, bn.bias.grad) < 5 * tol
+        bn.eval(); bn_d.eval()
+        op.forward(yv, ov, False)
+        assert _rel(ov.nchw().float(), F.leaky_relu(bn(y), 0.1).detach()) < tol
+
+
+def _flownets_pair(prec, shape, seed=3):
+    import mireg
+    m = mireg.FlowNetS(batchNorm=True, precision=prec)
+    nets.analytic_weights_(m)
+    m = m.to(DEV)
+    x = nets.analytic_input(shape, seed=seed)
+    return m, x
+
+
+def test_flownets_fp32_golden_config1(golden):
+    g = golden("g1_flownets_c1_4x64")
+    m, x = _flownets_pair("fp32", (4, 2, 64, 64))
+    m.train()
+    xd = x.to(DEV)
+    out = m(xd)
+    assert [tuple(o.shape) for o in out] == [(4, 2, 256, 256), (4, 2, 16, 16), (4, 2, 8, 8), (4, 2, 4, 4), (4, 2, 2, 2), (4, 2, 1, 1)]
+    for i in range(1, 6):
+        err = (out[i].detach().cpu() - torch.from_numpy(g[f"train_flow{i}"])).abs().max().item()
+        assert err < 1e-4, (i, err)
+    assert (out[0].detach().cpu()[:, :, ::8, ::8] - torch.from_numpy(g["train_flow0_s8"])).abs().max().item() < 1e-4
+    obj = sum((f * torch.cos(torch.arange(f.numel(), dtype=torch.float32).reshape(f.shape) * 0.01).to(DEV)).sum() for f in out)
+    obj.backward()
+    P = dict(m.named_parameters())
+    for k in ("conv1.0.weight", "conv3_1.1.weight", "conv3_1.1.bias", "predict_flow6.weight", "upsampled_flow6_to_5.weight",
+              "predict_flow2.weight"):
+        want = torch.from_numpy(g["grad_" + k])
+        assert _rel(P[k].grad, want) < 2e-3, k
+    for k in ("conv6_1.0.weight", "deconv5.0.weight", "conv2.0.weight", "deconv2.0.weight"):
+        assert abs(P[k].grad.double().norm().item() / float(g["gradnorm_" + k]) - 1) < 2e-3, k
+        assert _rel(P[k].grad.flatten()[:64], torch.from_numpy(g["gradhead_" + k])) < 5e-3, k
+    assert _rel(m.conv2[1].running_mean, torch.from_numpy(g["bn_running_mean_conv2"])) < 1e-4
+    m.eval()
+    out = m(xd)
+    assert len(out) == 2
+    assert (out[1].cpu() - torch.from_numpy(g["eval_flow1"])).abs().max().item() < 1e-4
+
+
+def test_flownets_fp32_golden_256(golden):
+    g = golden("g1_flownets_c2_2x256")
+    m, x = _flownets_pair("fp32", (2, 2, 256, 256))
+    m.train()
+    out = m(x.to(DEV))
+    for i in range(2, 6):
+        assert (out[i].detach().cpu() - torch.from_numpy(g[f"train_flow{i}"])).abs().max().item() < 1e-4, i
+    for i in (0, 1):
+        assert (out[i].detach().cpu()[:, :, ::8, ::8] - torch.from_numpy(g[f"train_flow{i}_s8"])).abs().max().item() < 1e-4, i
+        assert abs(out[i].detach().double().sum().item() - float(g[f"train_flow{i}_sum"])) < 1e-3 * max(1.0, float(g[f"train_flow{i}_abssum"]))
+
+
+def test_flownets_bf16_close_to_fp32():
+    m32, x = _flownets_pair("fp32", (2, 2, 256, 256))
+    m16, _ = _flownets_pair("bf16", (2, 2, 256, 256))
+    m32.train(); m16.train()
+    a, b = m32(x.to(DEV)), m16(x.to(DEV))
+    for fa, fb in zip(a, b):
+        assert _rel(fb.detach(), fa.detach()) < 6e-2
