@@ -292,11 +292,16 @@ class AffModel(nn.Module):
         return para, ops.affine_grid_sample_3d(moving, para)
 
 
+def _hash_uniform(idx: torch.Tensor, salt: float) -> torch.Tensor:
+    """RNG-free pseudo-random numbers in (-1, 1) from the element index (float64 sin hash)."""
+    return 2.0 * torch.frac(torch.sin(idx * 12.9898 + salt * 78.233) * 43758.5453).abs() - 1.0
+
+
 def analytic_weights_(model: nn.Module, scale: float = 1.0) -> None:
-    """Deterministic, RNG-free weights so 150 MB checkpoints never need
-    committing: conv weights ~ kaiming-sized sinusoids, BN affine near (1, 0),
-    running stats near (0, 1).  gen_golden.py applies this same function to the
-    reference model (state_dict keys match), so both sides get equal weights."""
+    """Deterministic, RNG-free weights so 150 MB checkpoints never need committing: conv weights are
+    hashed-uniform with the kaiming variance (well-conditioned like a fresh init), BN affine near (1, 0),
+    running stats near (0, 1).  gen_golden.py applies this same function to the reference model
+    (state_dict keys match), so both sides get identical weights."""
     with torch.no_grad():
         for li, (name, t) in enumerate(model.state_dict().items()):
             n = t.numel()
@@ -305,18 +310,18 @@ def analytic_weights_(model: nn.Module, scale: float = 1.0) -> None:
                 continue
             if t.dim() >= 3:  # conv / deconv weights
                 fan_in = n // t.shape[0]
-                amp = scale * (2.0 / max(fan_in, 1)) ** 0.5 * 1.2
-                vals = amp * torch.sin(0.37 * idx + 0.11 * li) * torch.cos(0.013 * idx + li)
+                amp = scale * (2.0 / max(fan_in, 1)) ** 0.5 * 3 ** 0.5
+                vals = amp * _hash_uniform(idx, li + 1)
             elif name.endswith("running_var"):
-                vals = 1.0 + 0.2 * torch.sin(0.5 * idx + li)
+                vals = 1.0 + 0.2 * _hash_uniform(idx, li + 1)
             elif name.endswith("running_mean"):
-                vals = 0.05 * torch.sin(0.3 * idx + li)
+                vals = 0.05 * _hash_uniform(idx, li + 1)
             elif name.endswith("weight") and t.dim() == 1:  # BN gamma
-                vals = 1.0 + 0.1 * torch.sin(0.7 * idx + li)
+                vals = 1.0 + 0.1 * _hash_uniform(idx, li + 1)
             elif t.dim() == 2:  # linear
-                vals = 1e-3 * torch.sin(0.37 * idx + li)
-            else:  # biases
-                vals = 0.02 * torch.sin(0.9 * idx + li)
+                vals = 1e-3 * _hash_uniform(idx, li + 1)
+            else:  # biases (conv bias, BN beta)
+                vals = 0.05 * _hash_uniform(idx, li + 1)
             t.copy_(vals.reshape(t.shape).to(t.dtype))
 
 

@@ -168,6 +168,37 @@ def test_batchnorm_lrelu(prec):
         assert _rel(ov.nchw().float(), F.leaky_relu(bn(y), 0.1).detach()) < tol
 
 
+def _check_flows(out, g, mode):
+    """|mireg - reference| <= 1e-4 * max(1, scale) + 4 * noise, where noise is the reference's OWN fp32 rounding
+    distance from a float64 evaluation (stored in the fixture): BatchNorm over the 4..32 samples of the deepest
+    levels amplifies rounding, and no fp32 implementation can match another more tightly than that."""
+    for i, f in enumerate(out):
+        f = f.detach().cpu()
+        noise = float(g[f"noise_flow{i}"]) if f"noise_flow{i}" in g.files else 0.0
+        if f"{mode}_flow{i}" in g.files:
+            want = torch.from_numpy(g[f"{mode}_flow{i}"])
+        else:
+            want, f = torch.from_numpy(g[f"{mode}_flow{i}_s8"]), f[:, :, ::8, ::8]
+        err, scale = (f - want).abs().max().item(), want.abs().max().item()
+        assert err <= 1e-4 * max(1.0, scale) + 4 * noise, (i, err, scale, noise)
+
+
+def _check_grads(m, g):
+    """relative L2 of each pinned parameter gradient vs the reference: <= 5e-3 + 8 * (reference's own fp32 noise
+    vs float64).  The 5e-3 floor covers LeakyReLU kink flips: one pre-activation within rounding of 0 flips a
+    0.1/1.0 slope and moves the L2 norm of a 1e5-element gradient by ~3e-3 in ANY fp32 implementation."""
+    P = dict(m.named_parameters())
+    keys = [k[5:] for k in g.files if k.startswith("grad_") and k != "grad_x_s4"]
+    assert len(keys) >= 10
+    for k in keys:
+        want = torch.from_numpy(g["grad_" + k]).double()
+        got = P[k].grad.detach().cpu().flatten()[:want.numel()].double()
+        rel = ((got - want).norm() / want.norm()).item()
+        tol = 5e-3 + 8 * float(g["gradnoise_" + k])
+        assert rel <= tol, (k, rel, tol)
+        assert abs(P[k].grad.double().norm().item() / float(g["gradnorm_" + k]) - 1) <= tol, k
+
+
 def _flownets_pair(prec, shape, seed=3):
     import mireg
     m = mireg.FlowNetS(batchNorm=True, precision=prec)
@@ -184,25 +215,16 @@ def test_flownets_fp32_golden_config1(golden):
     xd = x.to(DEV)
     out = m(xd)
     assert [tuple(o.shape) for o in out] == [(4, 2, 256, 256), (4, 2, 16, 16), (4, 2, 8, 8), (4, 2, 4, 4), (4, 2, 2, 2), (4, 2, 1, 1)]
-    for i in range(1, 6):
-        err = (out[i].detach().cpu() - torch.from_numpy(g[f"train_flow{i}"])).abs().max().item()
-        assert err < 1e-4, (i, err)
-    assert (out[0].detach().cpu()[:, :, ::8, ::8] - torch.from_numpy(g["train_flow0_s8"])).abs().max().item() < 1e-4
+    _check_flows(out, g, "train")
     obj = sum((f * torch.cos(torch.arange(f.numel(), dtype=torch.float32).reshape(f.shape) * 0.01).to(DEV)).sum() for f in out)
     obj.backward()
-    P = dict(m.named_parameters())
-    for k in ("conv1.0.weight", "conv3_1.1.weight", "conv3_1.1.bias", "predict_flow6.weight", "upsampled_flow6_to_5.weight",
-              "predict_flow2.weight"):
-        want = torch.from_numpy(g["grad_" + k])
-        assert _rel(P[k].grad, want) < 2e-3, k
-    for k in ("conv6_1.0.weight", "deconv5.0.weight", "conv2.0.weight", "deconv2.0.weight"):
-        assert abs(P[k].grad.double().norm().item() / float(g["gradnorm_" + k]) - 1) < 2e-3, k
-        assert _rel(P[k].grad.flatten()[:64], torch.from_numpy(g["gradhead_" + k])) < 5e-3, k
+    _check_grads(m, g)
     assert _rel(m.conv2[1].running_mean, torch.from_numpy(g["bn_running_mean_conv2"])) < 1e-4
     m.eval()
     out = m(xd)
     assert len(out) == 2
-    assert (out[1].cpu() - torch.from_numpy(g["eval_flow1"])).abs().max().item() < 1e-4
+    want = torch.from_numpy(g["eval_flow1"])
+    assert (out[1].cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
 
 
 def test_flownets_fp32_golden_256(golden):
@@ -210,17 +232,24 @@ def test_flownets_fp32_golden_256(golden):
     m, x = _flownets_pair("fp32", (2, 2, 256, 256))
     m.train()
     out = m(x.to(DEV))
-    for i in range(2, 6):
-        assert (out[i].detach().cpu() - torch.from_numpy(g[f"train_flow{i}"])).abs().max().item() < 1e-4, i
-    for i in (0, 1):
-        assert (out[i].detach().cpu()[:, :, ::8, ::8] - torch.from_numpy(g[f"train_flow{i}_s8"])).abs().max().item() < 1e-4, i
-        assert abs(out[i].detach().double().sum().item() - float(g[f"train_flow{i}_sum"])) < 1e-3 * max(1.0, float(g[f"train_flow{i}_abssum"]))
+    _check_flows(out, g, "train")
+    obj = sum((f * torch.cos(torch.arange(f.numel(), dtype=torch.float32).reshape(f.shape) * 0.01).to(DEV)).sum() for f in out)
+    obj.backward()
+    _check_grads(m, g)
 
 
 def test_flownets_bf16_close_to_fp32():
-    m32, x = _flownets_pair("fp32", (2, 2, 256, 256))
-    m16, _ = _flownets_pair("bf16", (2, 2, 256, 256))
+    """bf16 operands / fp32 accumulate vs the exact-fp32 engine on a realistically conditioned case
+    (reference init = kaiming, B=8 so the deepest BatchNorm sees 128 samples): relative L2 per flow < 5e-2."""
+    import mireg
+    torch.manual_seed(0)
+    m32 = mireg.FlowNetS(True, precision="fp32").to(DEV)
+    m16 = mireg.FlowNetS(True, precision="bf16").to(DEV)
+    m16.load_state_dict(m32.state_dict())
+    x = nets.analytic_input((8, 2, 256, 256), seed=4).to(DEV)
     m32.train(); m16.train()
-    a, b = m32(x.to(DEV)), m16(x.to(DEV))
-    for fa, fb in zip(a, b):
-        assert _rel(fb.detach(), fa.detach()) < 6e-2
+    a, b = m32(x), m16(x)
+    for i, (fa, fb) in enumerate(zip(a, b)):
+        rel = ((fb - fa).double().norm() / fa.double().norm()).item()
+        print("bf16 vs fp32 flow", i, "rel L2", rel)
+        assert rel < 5e-2, (i, rel)
