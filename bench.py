@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the registration hot path on MI355X.
+
+metric  : registration slice-pairs / s, whole job (BASELINE.json), one step = one training step of
+          FlowNetS (forward + stn warps + OFEloss + backward + gradient all-reduce + Adam) on a
+          batch of synthetic 256x256 pairs, 24 pairs per GPU (weak scaling), bf16 operands.
+usage   : python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+output  : ONE JSON line on rank 0 (see DESIGN.md section 7 for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+CONV_GFLOP_PER_PAIR_FWD = {"flownets": 10.114}     # SURVEY section 8d (hook-measured on the reference)
+
+
+def cpu_baseline(B, size, steps, seed):
+    """The CPU oracle (plain torch fp32 restatement of the reference path) timed on this host."""
+    from oracle import nets, ops as oops
+    from mireg.synth import make_pairs
+    torch.manual_seed(seed)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    model = nets.OpticalFlowReg("flownets")
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), 1e-4, betas=(0.9, 0.999), eps=1e-4)
+    x, _ = make_pairs(B, size, seed)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        flows, warped, _, _ = model(x)
+        loss = oops.ofe_loss(flows, warped, x[:, 0:1])[3]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": B / med, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps (after 1 warm-up) of the CPU oracle, FlowNetS B={B} {size}x{size} fp32, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=24, help="pairs per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--model", default="flownets")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    import mireg
+    from mireg.engine import PROFILER
+    from mireg.synth import make_pairs
+
+    torch.manual_seed(6)
+    model = mireg.opticalFlowReg(args.model, precision=args.precision).to(dev)
+    if world > 1:  # identical replicas
+        for p in model.parameters():
+            torch.distributed.broadcast(p.data, 0)
+        for b in model.buffers():
+            torch.distributed.broadcast(b, 0)
+    trainer = mireg.RegistrationTrainer(model, lr=1e-4, eps=1e-4, use_graph=not args.no_graph)
+    x_cpu, seg_cpu = make_pairs(args.batch, args.size, seed=6 + rank)
+    x = x_cpu.to(dev)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 3)):     # >= 3: two eager steps size the workspaces, then the graph is captured
+        trainer.step(x)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = trainer.step(x)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_vals = [float(v) for v in losses.tolist()]
+    pairs = args.batch * world * args.steps
+
+    # ---- roofline leg: per-launch timing of the MFMA contractions (events on the launch stream) ------------
+    roof = None
+    if rank == 0:
+        trainer.use_graph = False
+        PROFILER.enabled, PROFILER.records = True, []
+        for _ in range(3):
+            trainer._fwd_bwd()
+        summ = PROFILER.summary()
+        PROFILER.enabled = False
+        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        tot_fl = sum(v["flops"] for v in summ.values())
+        tot_ms = sum(v["ms"] for v in summ.values())
+        peak = PEAK_TFLOPS[args.precision]
+        ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None,
+                "avg_launch_us": round(dom[1]["ms"] * 1e3 / dom[1]["launches"], 2), "launches_per_step": dom[1]["launches"] // 3,
+                "all_contractions": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_step": round(tot_ms / 3, 3),
+                                     "gflop_per_step": round(tot_fl / 3 / 1e9, 1)},
+                "families": {k: {"launches_per_step": v["launches"] // 3, "ms_per_step": round(v["ms"] / 3, 3),
+                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in summ.items()}}
+
+    # ---- quality leg: warped Dice of the (random-init, K-step-trained) model, GPU vs CPU oracle ---------------
+    dice = None
+    if rank == 0:
+        try:
+            from oracle import nets as onets, ops as oops
+            nb = 4
+            xe, se = make_pairs(nb, args.size, seed=8, magnitude=(0.5, 1.0))
+            ev = trainer.evaluate(xe.to(dev), se.to(dev))
+            om = onets.OpticalFlowReg(args.model)
+            om.load_state_dict(model.state_dict())
+            om.eval()
+            with torch.no_grad():
+                _, _, wseg, _ = om(xe, se)
+            d_cpu = [oops.dice_average(se[j, 0], wseg[j, 0]) for j in range(nb)]
+            d_id = [oops.dice_average(se[j, 0], se[j, 1]) for j in range(nb)]
+            dice = {"gpu_mean": round(float(ev["dice"].mean()), 5), "cpu_oracle_mean": round(sum(d_cpu) / nb, 5),
+                    "unregistered_mean": round(sum(d_id) / nb, 5), "pairs": nb,
+                    "note": "synthetic 4-label masks, weights after the timed steps (random init, no dataset)"}
+        except Exception as e:  # the quality leg must never break the timing line
+            dice = {"error": repr(e)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.batch, args.size, args.cpu_steps, seed=6)
+
+    if rank == 0:
+        out = {"metric": "registration slice-pairs/s (FlowNetS train step: fwd + warp + OFEloss + bwd + all-reduce + Adam)",
+               "value": round(pairs / dt, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": f"configs[1]: {args.model} {args.size}x{args.size} slice pairs, batch {args.batch}/GPU, "
+                                      f"{args.precision} operands fp32 accumulate, train step", "global_batch": args.batch * world,
+                          "parallelism": f"dp{world}", "hipgraph": not args.no_graph},
+               "loss": {"photo": loss_vals[0], "corr": loss_vals[1], "smooth": loss_vals[2], "total": loss_vals[3]},
+               "roofline": roof, "cpu_baseline": cpu, "dice": dice}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -121,6 +121,38 @@ class Workspace:
 NUM_CU = 256
 
 
+class LaunchProfiler:
+    """Optional per-launch timing of the MFMA contractions (bench.py roofline leg): brackets every
+    mireg_conv_gemm / mireg_conv_wgrad launch with events on the launch stream and books its algorithmic FLOPs."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (kernel family, flops, start event, stop event)
+
+    def launch(self, fn: str, desc, family: str, flops: float) -> None:
+        if not self.enabled:
+            _lib.call(fn, ctypes.byref(desc), _stream())
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.call(fn, ctypes.byref(desc), _stream())
+        b.record()
+        self.records.append((family, flops, a, b))
+
+    def summary(self) -> Dict[str, dict]:
+        torch.cuda.synchronize()
+        out: Dict[str, dict] = {}
+        for fam, fl, a, b in self.records:
+            d = out.setdefault(fam, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += fl
+            d["ms"] += a.elapsed_time(b)
+        return out
+
+
+PROFILER = LaunchProfiler()
+
+
 def _split_for(tiles: int, nk: int, cap: int = 32) -> int:
     if tiles >= NUM_CU or nk < 8:
         return 1
@@ -211,7 +243,13 @@ class ConvLayer:
         d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
         d.slope, d.accumulate = slope, int(accumulate)
         self._finish(d, x.B * Ho * Wo, self.Co, self.Kf, True)
-        _lib.call("mireg_conv_gemm", ctypes.byref(d), _stream())
+        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Co, d.split_k),
+                        2.0 * x.B * Ho * Wo * self.Co * self.kh * self.kw * self.Ci)
+
+    @staticmethod
+    def _family(N: int, split: int) -> str:
+        bn = 128 if N > 64 else (64 if N > 32 else 32)
+        return f"conv_gemm_kernel<128,{bn}>" + ("+splitk" if split > 1 else "")
 
     @staticmethod
     def _fill_out(d, y, y32, yH, yW, mul_y, mul_x, off_y, off_x):
@@ -249,7 +287,8 @@ class ConvLayer:
             d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
             d.slope, d.accumulate = slope, int(accumulate)
             self._finish(d, g.B * gH * gW, self.Ci, c["K"], True)
-            _lib.call("mireg_conv_gemm", ctypes.byref(d), _stream())
+            PROFILER.launch("mireg_conv_gemm", d, self._family(self.Ci, d.split_k),
+                            2.0 * g.B * gH * gW * self.Ci * c["nty"] * c["ntx"] * self.Co)
 
     def plan_wgrad(self, x: View, dy: View) -> None:
         """Size the persistent split-K slab for dW[co][(ky,kx,ci_pad)] = sum_pix dy[pix][co] x[pix@tap][ci]."""
@@ -258,8 +297,9 @@ class ConvLayer:
         nk = (dy.rows + bk - 1) // bk
         self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((2 * NUM_CU + tiles - 1) // tiles, max(nk // 2, 1), 128))
         self.wgrad_slab = torch.empty(self.wgrad_split, self.Co, self.Kf, device=self.ws.device, dtype=F32)
-        self.grad_w = torch.zeros_like(self.weight, dtype=F32)
-        if self.bias is not None:
+        if self.grad_w is None:
+            self.grad_w = torch.zeros_like(self.weight, dtype=F32)
+        if self.bias is not None and self.grad_b is None:
             self.grad_b = torch.zeros_like(self.bias, dtype=F32)
 
     def run_wgrad(self, x: View, dy: View) -> None:
@@ -276,7 +316,8 @@ class ConvLayer:
         d.g_H, d.g_W, d.n_img = dy.H, dy.W, dy.B
         d.y, d.y_ld, d.N = dy.ptr, dy.ld, self.Co
         d.split_k, d.slab, d.dtype = self.wgrad_split, self.wgrad_slab.data_ptr(), self.ws.code
-        _lib.call("mireg_conv_wgrad", ctypes.byref(d), _stream())
+        PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_kernel<128,128>",
+                        2.0 * dy.rows * self.Co * self.kh * self.kw * self.Ci)
 
     def run_bias_grad(self, dy: View, accumulate: bool = False) -> None:
         if self.bias is None:

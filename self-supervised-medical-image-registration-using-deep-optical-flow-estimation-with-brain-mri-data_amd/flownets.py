@@ -65,6 +65,25 @@ class PredictorEngineBase:
             self._unpack_table, self._unpack_n = upload_table(jobs, self.ws.device), len(jobs)
         _lib.call("mireg_unpack_wgrad", self._unpack_table.data_ptr(), self._unpack_n, _stream())
 
+    def bind_flat_grads(self, params: Sequence[nn.Parameter], flat: torch.Tensor) -> None:
+        """Make every gradient buffer a view of `flat` (parameter order), so one RCCL all-reduce / one Adam
+        launch covers the whole model."""
+        off, o = {}, 0
+        for p in params:
+            off[id(p)] = o
+            o += p.numel()
+        assert o == flat.numel()
+
+        def view(p):
+            return flat[off[id(p)]:off[id(p)] + p.numel()].view(p.shape)
+        for l in self.layers.values():
+            l.grad_w = view(l.weight)
+            if l.bias is not None:
+                l.grad_b = view(l.bias)
+        for b in self.bns.values():
+            b.grad_g, b.grad_b = view(b.bn.weight), view(b.bn.bias)
+        self._unpack_table = None
+
     def param_grads(self) -> Dict[int, torch.Tensor]:
         """id(parameter) -> persistent fp32 gradient buffer (torch layout)."""
         out = {}

@@ -1,0 +1,236 @@
+"""Fused training / evaluation step of the registration hot path (reference train.py:41-65 `epoch`).
+
+One call = predictor forward -> stn warp at every scale (+ loss moments fused into the warp kernel)
+-> OFEloss -> backward of all of it -> (RCCL gradient all-reduce) -> Adam, as one hand-scheduled
+kernel sequence over persistent buffers; no autograd graph, no host synchronisation, optionally
+replayed from a hipGraph.  Numerically it is the same computation as
+
+    flows, warped, _, _ = model(imgs); p, c, s, loss = OFEloss(flows, warped, fixed)
+    optimizer.zero_grad(); loss.backward(); optimizer.step()        # Adam(lr, (.9,.999), eps=1e-4)
+
+(tests/test_trainer_gpu.py checks the two against each other and against the CPU oracle).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import AdamJob, F32, _stream, upload_table
+
+
+def flatten_parameters(module: nn.Module) -> torch.Tensor:
+    """Re-home every parameter as a view of one flat fp32 buffer (values preserved)."""
+    params = list(module.parameters())
+    dev = params[0].device
+    flat = torch.empty(sum(p.numel() for p in params), device=dev, dtype=F32)
+    o = 0
+    for p in params:
+        n = p.numel()
+        flat[o:o + n].copy_(p.data.reshape(-1))
+        p.data = flat[o:o + n].view(p.shape)
+        o += n
+    return flat
+
+
+class FusedRegLoss:
+    """stn warp + OFEloss forward/backward on engine buffers (K9-K13 fused; no autograd)."""
+
+    def __init__(self, B: int, H: int, W: int, sizes: Sequence[tuple], device, lamb_da=0.5, gamma=100.0, zeta=100.0):
+        self.B, self.H, self.W, self.sizes, self.dev = B, H, W, list(sizes), device
+        self.hyper = (float(lamb_da), float(gamma), float(zeta))
+        n = len(sizes)
+        self.n = n
+        z = lambda *s: torch.zeros(*s, device=device, dtype=F32)
+        self.moving_r = [z(B, 1, h, w) for h, w in sizes]
+        self.fixed_r = [z(B, 1, h, w) for h, w in sizes]
+        self.warped = [z(B, 1, h, w) for h, w in sizes]
+        self.gwarped = [z(B, 1, h, w) for h, w in sizes]
+        self.gflow = [z(B, 2, h, w) for h, w in sizes]
+        self.sums = torch.zeros(n, 8, device=device, dtype=torch.float64)
+        self.npix = torch.tensor([B * h * w for h, w in sizes], dtype=torch.int64, device=device)
+        self.out4 = torch.zeros(4, device=device, dtype=torch.float64)
+        self.g4 = torch.tensor([0.0, 0.0, 0.0, 1.0], device=device, dtype=torch.float64)
+        self.coef = torch.zeros(n, 8, device=device, dtype=F32)
+
+    def forward(self, x: torch.Tensor, flows: Sequence[torch.Tensor]) -> torch.Tensor:
+        """x: (B,2,H,W) contiguous fp32 [fixed, moving]; flows[i]: logical (B,2,h,w) fp32 (any pixel stride)."""
+        B, H, W, st = self.B, self.H, self.W, _stream()
+        HW = H * W
+        fixed_ptr, moving_ptr = x.data_ptr(), x.data_ptr() + HW * 4
+        self.sums.zero_()
+        for i, (h, w) in enumerate(self.sizes):
+            _lib.call("mireg_resize_bilinear_fwd", moving_ptr, self.moving_r[i].data_ptr(), B, 1, H, W, h, w,
+                      2 * HW, HW, 1, h * w, h * w, 1, 1, st)
+            _lib.call("mireg_resize_bilinear_fwd", fixed_ptr, self.fixed_r[i].data_ptr(), B, 1, H, W, h, w,
+                      2 * HW, HW, 1, h * w, h * w, 1, 0, st)
+            f = flows[i]
+            sb, sc, sy, sx = f.stride()
+            sp = sx if w > 1 else (sy if h > 1 else 1)
+            _lib.call("mireg_stn_warp_fwd", f.data_ptr(), sb, sc, sp, self.moving_r[i].data_ptr(),
+                      self.fixed_r[i].data_ptr(), self.warped[i].data_ptr(), self.sums[i].data_ptr(), B, 1, h, w, st)
+            _lib.call("mireg_smoothness_fwd", f.data_ptr(), sb, sc, sp, self.sums[i, 6:].data_ptr(), B, h, w, st)
+        return self.sums
+
+    def _npix(self, B_global: Optional[int]) -> torch.Tensor:
+        if not B_global or B_global == self.B:
+            return self.npix
+        if getattr(self, "_npix_g", None) is None:
+            self._npix_g = self.npix * (B_global // self.B)
+        return self._npix_g
+
+    def finalize(self, B_global: Optional[int] = None) -> torch.Tensor:
+        lamb_da, gamma, zeta = self.hyper
+        _lib.call("mireg_ofe_finalize", self.sums.data_ptr(), self._npix(B_global).data_ptr(), self.n, B_global or self.B, lamb_da,
+                  gamma, zeta, self.out4.data_ptr(), _stream())
+        return self.out4
+
+    def backward(self, flows: Sequence[torch.Tensor], B_global: Optional[int] = None) -> List[torch.Tensor]:
+        B, st = self.B, _stream()
+        lamb_da, gamma, zeta = self.hyper
+        _lib.call("mireg_ofe_bwd_coef", self.sums.data_ptr(), self._npix(B_global).data_ptr(), self.n, B_global or B, lamb_da,
+                  gamma, zeta, self.g4.data_ptr(), self.coef.data_ptr(), st)
+        for i, (h, w) in enumerate(self.sizes):
+            f = flows[i]
+            sb, sc, sy, sx = f.stride()
+            sp = sx if w > 1 else (sy if h > 1 else 1)
+            _lib.call("mireg_loss_bwd", self.warped[i].data_ptr(), self.fixed_r[i].data_ptr(), self.coef[i].data_ptr(),
+                      self.gwarped[i].data_ptr(), B * h * w, st)
+            g = self.gflow[i]
+            _lib.call("mireg_stn_warp_bwd", f.data_ptr(), sb, sc, sp, self.moving_r[i].data_ptr(),
+                      self.gwarped[i].data_ptr(), g.data_ptr(), 2 * h * w, h * w, 1, 0.0, B, 1, h, w, st)
+            _lib.call("mireg_smoothness_bwd", f.data_ptr(), sb, sc, sp, self.coef[i].data_ptr(), g.data_ptr(),
+                      2 * h * w, h * w, 1, 1.0, B, h, w, st)
+        return self.gflow
+
+
+class RegistrationTrainer:
+    """Owns the fused step for one opticalFlowReg on one GPU (one process per GPU under DP)."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-4,
+                 lamb_da: float = 0.5, gamma: float = 100.0, zeta: float = 100.0, use_graph: bool = True,
+                 process_group=None, sync_loss_stats: bool = False):
+        self.model = model
+        self.predictor = model.predictor
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.loss_hyper = (lamb_da, gamma, zeta)
+        self.use_graph = use_graph
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.sync_loss_stats = sync_loss_stats and self.world > 1
+        self.flat_p = flatten_parameters(model)
+        dev = self.flat_p.device
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self._adam_tab = upload_table([AdamJob(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                               self.flat_v.data_ptr(), self.flat_p.numel())], dev)
+        self.eng = None
+        self.loss = None
+        self.x_static = None
+        self._graph_fb = None
+        self._graph_opt = None
+        self._warm = 0
+
+    # ------------------------------------------------------------------------------------------
+    def _setup(self, x: torch.Tensor) -> None:
+        self.predictor.train()
+        self.eng = self.predictor.engine_for(x)
+        self.eng.bind_flat_grads(list(self.model.parameters()), self.flat_g)
+        self.x_static = torch.empty_like(x, memory_format=torch.contiguous_format)
+        flows = self.eng.forward(self.x_static.copy_(x), True)
+        sizes = [tuple(f.shape[2:]) for f in flows]
+        B, _, H, W = x.shape
+        self.loss = FusedRegLoss(B, H, W, sizes, x.device, *self.loss_hyper)
+
+    def _fwd_bwd(self) -> None:
+        flows = self.eng.forward(self.x_static, True)
+        self.loss.forward(self.x_static, flows)
+        Bg = self.loss.B * self.world if self.sync_loss_stats else None
+        if self.sync_loss_stats:
+            torch.distributed.all_reduce(self.loss.sums, group=self.pg)
+        self.loss.finalize(Bg)
+        gflows = self.loss.backward(flows, Bg)
+        self.eng.backward(gflows)
+
+    def _optim(self) -> None:
+        _lib.call("mireg_adam_step", self._adam_tab.data_ptr(), 1, self.step_dev.data_ptr(), self.lr, self.betas[0],
+                  self.betas[1], self.eps, 1.0 / self.world, _stream())
+
+    def step(self, x: torch.Tensor) -> torch.Tensor:
+        """One optimizer step on batch x (B,2,H,W) fp32 on device.  Returns the device tensor
+        (photo, corr, smooth, total) in float64 WITHOUT synchronising (call .tolist() when needed)."""
+        if self.eng is None:
+            self._setup(x)
+        self.x_static.copy_(x)
+        graphable = self.use_graph and not self.sync_loss_stats
+        if graphable and self._warm >= 2:
+            if self._graph_fb is None:
+                self._capture()
+            self._graph_fb.replay()
+            if self.world > 1:
+                torch.distributed.all_reduce(self.flat_g, group=self.pg)
+            self._graph_opt.replay()
+        else:
+            self._fwd_bwd()
+            if self.world > 1:
+                torch.distributed.all_reduce(self.flat_g, group=self.pg)
+            self._optim()
+            self._warm += 1
+        return self.loss.out4
+
+    def _capture(self) -> None:
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._graph_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_fb, stream=s):
+                self._fwd_bwd()
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt, stream=s):
+                self._optim()
+        torch.cuda.current_stream().wait_stream(s)
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def evaluate(self, x: torch.Tensor, segs: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Eval forward + OFEloss (+ warped-segmentation Dice per sample), reference inference.py:43-68."""
+        from . import ops
+        self.model.eval()
+        flows, warped, wseg, _ = self.model(x, segs)
+        p, c, s, t = ops.OFEloss(flows, warped, x[:, 0:1].contiguous(), *self.loss_hyper)
+        out = {"loss": torch.stack((p, c, s, t)), "flow": flows[0]}
+        if segs is not None:
+            out["dice"] = ops.dice_batch(segs[:, 0:1].float().contiguous(), wseg)
+        self.model.train()
+        return out
+
+    def optimizer_state_dict(self) -> dict:
+        """torch.optim.Adam-compatible state (reference checkpoints store optimizer_state_dict, train.py:183-188)."""
+        state, o = {}, 0
+        step = self.step_dev.to(torch.float32).cpu().reshape(())
+        for i, p in enumerate(self.model.parameters()):
+            n = p.numel()
+            state[i] = {"step": step.clone(), "exp_avg": self.flat_m[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.flat_v[o:o + n].view(p.shape).clone()}
+            o += n
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(state)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        o = 0
+        for i, p in enumerate(self.model.parameters()):
+            n = p.numel()
+            st = sd["state"].get(i)
+            if st is not None:
+                self.flat_m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                self.step_dev.fill_(int(st["step"]))
+            o += n
