@@ -22,17 +22,34 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skill
 CONV_GFLOP_PER_PAIR_FWD = {"flownets": 10.114}     # SURVEY section 8d (hook-measured on the reference)
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_share():
+    """CPUs this process may really use: cgroup quota if present, else the affinity mask."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(B, size, steps, seed):
     """The CPU oracle (plain torch fp32 restatement of the reference path) timed on this host."""
     from oracle import nets, ops as oops
     from mireg.synth import make_pairs
     torch.manual_seed(seed)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = min(cpu_share(), 64)
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads")
     model = nets.OpticalFlowReg("flownets")
     model.train()
     opt = torch.optim.Adam(model.parameters(), 1e-4, betas=(0.9, 0.999), eps=1e-4)
@@ -45,11 +62,14 @@ def cpu_baseline(B, size, steps, seed):
         opt.zero_grad()
         loss.backward()
         opt.step()
+        log(f"cpu baseline step {i}: {time.perf_counter() - t0:.2f} s")
         if i > 0:
             times.append(time.perf_counter() - t0)
+        if i >= 1 and sum(times) > 40:      # bounded sample
+            break
     med = sorted(times)[len(times) // 2]
     return {"value": B / med, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} train steps (after 1 warm-up) of the CPU oracle, FlowNetS B={B} {size}x{size} fp32, median"}
+            "sample": f"{len(times)} train steps (after 1 warm-up) of the CPU oracle, FlowNetS B={B} {size}x{size} fp32, median"}
 
 
 def main():
@@ -99,9 +119,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    log(f"rank {rank}/{world}: model ready, warm-up")
     for _ in range(max(args.warmup, 3)):     # >= 3: two eager steps size the workspaces, then the graph is captured
         trainer.step(x)
     sync()
+    log("timed region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = trainer.step(x)
@@ -116,6 +138,7 @@ def main():
 
     # ---- roofline leg: per-launch timing of the MFMA contractions (events on the launch stream) ------------
     roof = None
+    log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     if rank == 0:
         trainer.use_graph = False
         PROFILER.enabled, PROFILER.records = True, []
@@ -139,7 +162,9 @@ def main():
     # ---- quality leg: warped Dice of the (random-init, K-step-trained) model, GPU vs CPU oracle ---------------
     dice = None
     if rank == 0:
+        log("quality leg (Dice)")
         try:
+            torch.set_num_threads(min(cpu_share(), 64))
             from oracle import nets as onets, ops as oops
             nb = 4
             xe, se = make_pairs(nb, args.size, seed=8, magnitude=(0.5, 1.0))

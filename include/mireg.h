@@ -111,34 +111,40 @@ int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);
 
 
 /* ---- weight layout plumbing (torch layout <-> GEMM layouts), one launch for a table of jobs ---- */
-/* pack: dst[row][(ty*ntx+tx)*Cpad + c] = W[co][ci][ky0+sy*ty][kx0+sx*tx] (W = torch Conv2d layout
- * [Co][Ci][kh][kw] fp32, zero in every pad slot); kind 0: row=co,c=ci (FWD pack); kind 1: row=ci,c=co
- * (DGRAD pack, one job per output-pixel parity class).  ConvTranspose2d weights [Cin][Cout][kh][kw]
- * are the Conv2d weights of the adjoint convolution, so the same two packs serve deconvolutions.
- * unpack: grad[co][ci][ky][kx] (+)= sum_z slab[z][co][(ky*kw+kx)*Cpad + ci]; there src = slab,
- * dst = grad, rows = Co, ld = kh*kw*Cpad, sy = number of split-K slabs, kind = accumulate flag. */
+/* pack (one job per layer; W = torch Conv2d layout [Co][Ci][kh][kw] fp32, every pad slot zeroed):
+ *   FWD   pack  dst[co][(ky*kw+kx)*Cpad + ci]                                        (pitch ld)
+ *   DGRAD packs cls[c].dst[ci][(ty*ntx+tx)*Cop + co], ky = ky0 + stride*ty, kx = kx0 + stride*tx,
+ *         one per output-pixel parity class c (nclass = stride^2 <= 4)
+ * ConvTranspose2d weights [Cin][Cout][kh][kw] are the Conv2d weights of the adjoint convolution, so
+ * the same packs serve deconvolutions.
+ * unpack: grad[co][ci][ky][kx] (+)= sum_{z<nsplit} slab[z][co][(ky*kw+kx)*Cpad + ci]; src = slab, dst = grad. */
+typedef struct mireg_pack_class { void* dst; long ld; int ky0, kx0, nty, ntx; } mireg_pack_class;
 typedef struct mireg_pack_job {
   const float* src; void* dst;
   int Co, Ci, kh, kw;
-  int kind, Cpad, ky0, kx0, sy, sx, nty, ntx;
-  long ld; int rows;
+  int Cpad, Cop; long ld;
+  int stride, nclass;
+  mireg_pack_class cls[4];
+  int nsplit, accumulate;
+  int unit0;      /* first FWD-pack / unpack work unit of this job; units = Co * ceil(C/64), C = Cpad (pack) or Ci (unpack) */
+  int dunit0;     /* first DGRAD-pack block: blocks = sum_c nty_c*ntx_c * ceil(Cop/64) * ceil(Ci/64) */
 } mireg_pack_job;
-int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int dtype, hipStream_t stream);
-int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, hipStream_t stream);
+int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int total_units, int total_dgrad_units, int dtype,
+                       hipStream_t stream);
+int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, int total_units, hipStream_t stream);
 
 /* ---- K1 tail: BatchNorm2d (batch statistics in train mode) + LeakyReLU, FlowNetS/util.py:17-30 ---- */
-/* y is the raw convolution output [M][ld_y]; ss = [scale | shift | mean | rstd] (4*C floats);
- * sums = 2*C doubles of workspace (zeroed inside). */
-int mireg_bn_stats(const void* y, long ld_y, long M, int C, double* sums, int dtype, hipStream_t stream);
-int mireg_bn_finalize(const double* sums, long M, int C, const float* gamma, const float* beta,
-                      float* running_mean, float* running_var, float momentum, float eps, int training,
-                      float* ss, hipStream_t stream);
-int mireg_bn_apply(const void* y, long ld_y, void* out, long ld_o, const float* ss, long M, int C, float slope,
-                   int dtype, hipStream_t stream);
-/* da = gradient wrt the activated output; dy = gradient wrt the raw convolution output */
-int mireg_bn_bwd(const void* y, long ld_y, const void* da, long ld_da, void* dy, long ld_dy, const float* ss,
-                 double* sums, float* dgamma, float* dbeta, int acc_param_grads, long M, int C, float slope,
-                 int dtype, hipStream_t stream);
+/* y = raw convolution output [M][ld_y]; out = lrelu(bn(y)); ss = [scale | shift | mean | rstd] (4*C floats,
+ * kept for the backward pass); partial = workspace of MIREG_BN_MAX_BLOCKS * 2 * C floats (two-stage,
+ * deterministic reduction); running stats are updated in place when training (momentum, unbiased var). */
+#define MIREG_BN_MAX_BLOCKS 1024
+int mireg_bn_forward(const void* y, long ld_y, void* out, long ld_o, long M, int C, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                     int training, float slope, float* partial, float* ss, int dtype, hipStream_t stream);
+/* da = gradient wrt the activated output; dy = gradient wrt the raw convolution output; red = 2*C floats */
+int mireg_bn_backward(const void* y, long ld_y, const void* da, long ld_da, void* dy, long ld_dy, const float* ss,
+                      float* partial, float* red, float* dgamma, float* dbeta, int acc_param_grads, long M,
+                      int C, float slope, int dtype, hipStream_t stream);
 int mireg_lrelu_bwd(void* g, long ld_g, const void* a, long ld_a, long M, int C, float slope, int dtype,
                     hipStream_t stream);
 

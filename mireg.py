@@ -1,6 +1,12 @@
 """`import mireg` -> the package that lives in the (un-importably named) directory
-self-supervised-medical-image-registration-using-deep-optical-flow-estimation-with-brain-mri-data_amd/."""
+self-supervised-medical-image-registration-using-deep-optical-flow-estimation-with-brain-mri-data_amd/.
+
+`mireg` and every `mireg.<submodule>` resolve to the SAME module objects as the long-named package
+(an alias finder, not a second copy), so singletons such as the loaded C-ABI library are shared.
+"""
 import importlib
+import importlib.abc
+import importlib.util
 import os
 import sys
 
@@ -8,5 +14,25 @@ PACKAGE_DIR = "self-supervised-medical-image-registration-using-deep-optical-flo
 _root = os.path.dirname(os.path.abspath(__file__))
 if _root not in sys.path:
     sys.path.insert(0, _root)
+
+
+class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname == "mireg" or fullname.startswith("mireg."):
+            return importlib.util.spec_from_loader(fullname, self)
+        return None
+
+    def create_module(self, spec):
+        return importlib.import_module(PACKAGE_DIR + spec.name[len("mireg"):])
+
+    def exec_module(self, module):
+        pass
+
+
+if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
+    sys.meta_path.insert(0, _AliasFinder())
 _pkg = importlib.import_module(PACKAGE_DIR)
-sys.modules[__name__] = _pkg
+sys.modules["mireg"] = _pkg
+for _name, _mod in list(sys.modules.items()):
+    if _name.startswith(PACKAGE_DIR + "."):
+        sys.modules["mireg" + _name[len(PACKAGE_DIR):]] = _mod

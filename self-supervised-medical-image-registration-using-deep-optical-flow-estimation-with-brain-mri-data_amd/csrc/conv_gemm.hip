@@ -25,6 +25,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 namespace {
 
 struct alignas(16) Chunk { uint32_t w[4]; };
+// Tile loads must be GLOBAL (address space 1) loads: through a struct-passed pointer hipcc otherwise emits
+// flat_load, which also counts on lgkmcnt and serialises against the LDS fragment reads.
+template <typename T> __device__ __forceinline__ Chunk ldg_chunk(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint4 v = *reinterpret_cast<const __attribute__((address_space(1))) uint4*>(reinterpret_cast<uintptr_t>(p));
+  return Chunk{{v.x, v.y, v.z, v.w}};
+#else
+  return *reinterpret_cast<const Chunk*>(p);
+#endif
+}
 
 template <typename T> struct Cfg;
 template <> struct Cfg<float>  { static constexpr int CPC = 4, BK = 16; };   // elements per 16-B chunk, K per step
@@ -104,14 +114,14 @@ conv_gemm_kernel(const mireg_conv_desc p) {
     for (int c = 0; c < A_CH; ++c) {
       const int iy = a_iy0[c] + ty * p.step_y, ix = a_ix0[c] + tx * p.step_x;
       const bool ok = a_ok[c] && kvalid && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
-      ra[c] = ok ? *reinterpret_cast<const Chunk*>(xp + a_base[c] + ((long)iy * p.x_W + ix) * p.x_ld + cc * CPC) : zero;
+      ra[c] = ok ? ldg_chunk(xp + a_base[c] + ((long)iy * p.x_W + ix) * p.x_ld + cc * CPC) : zero;
     }
     const int k = kt * BK + kc * CPC;
 #pragma unroll
     for (int c = 0; c < B_CH; ++c) {
       const int nl = lrow + 64 * c, n = n0 + nl;
       const bool ok = nl < BN && n < p.N && k < K;
-      rb[c] = ok ? *reinterpret_cast<const Chunk*>(wp + (long)n * p.w_ld + k) : zero;
+      rb[c] = ok ? ldg_chunk(wp + (long)n * p.w_ld + k) : zero;
     }
     cc += 4;                                 // advance this thread's chunk by one K-step
     while (cc >= cpt) { cc -= cpt; if (++tx == p.taps_x) { tx = 0; ++ty; } }
@@ -315,7 +325,7 @@ conv_wgrad_kernel(const mireg_conv_desc p) {
     for (int c = 0; c < A_CH; ++c) {
       const int pix = kt * BK + a_prow[c];
       const bool ok = a_cok[c] && pix < P;
-      ra[c] = ok ? *reinterpret_cast<const Chunk*>(dyp + (long)pix * p.y_ld + m0 + a_col[c]) : zero;
+      ra[c] = ok ? ldg_chunk(dyp + (long)pix * p.y_ld + m0 + a_col[c]) : zero;
     }
 #pragma unroll
     for (int c = 0; c < B_CH; ++c) {
@@ -326,7 +336,7 @@ conv_wgrad_kernel(const mireg_conv_desc p) {
       const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
       const int iy = gy * p.mul_y + p.off_y + b_ty[c] * p.step_y, ix = gx * p.mul_x + p.off_x + b_tx[c] * p.step_x;
       ok = ok && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
-      rb[c] = ok ? *reinterpret_cast<const Chunk*>(xp + (((long)img * p.x_H + iy) * p.x_W + ix) * p.x_ld + b_ch[c]) : zero;
+      rb[c] = ok ? ldg_chunk(xp + (((long)img * p.x_H + iy) * p.x_W + ix) * p.x_ld + b_ch[c]) : zero;
     }
   };
   auto store_tiles = [&](int buf) {

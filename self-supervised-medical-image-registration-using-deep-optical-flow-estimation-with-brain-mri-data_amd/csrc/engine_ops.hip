@@ -1,9 +1,10 @@
 // engine_ops.hip -- the HBM-bound glue around the MFMA contractions (all NHWC [rows][ld] views):
-//   weight packing / gradient unpacking between torch layout and the GEMM layouts,
+//   weight packing / gradient unpacking between torch layout and the GEMM layouts (LDS-tiled transposes),
 //   train-mode BatchNorm2d + LeakyReLU(0.1) forward / backward (FlowNetS/util.py:17-30),
 //   LeakyReLU backward, fp32 <-> compute-dtype casts with accumulate, NCHW -> NHWC input staging,
-//   fused multi-tensor Adam exactly as train.py:129 configures it (eps = 1e-4).
-// Table-driven launches (one grid.y slot per job) keep the per-step launch count flat.
+//   fused Adam exactly as train.py:129 configures it (eps = 1e-4).
+// Every kernel streams 16-byte vectors through GLOBAL (address-space 1) accesses; reductions are two-stage
+// (per-block partial rows, then a tiny finalize) so they are deterministic and free of atomic contention.
 #include "mireg_common.h"
 #include "../../include/mireg.h"
 
@@ -11,121 +12,266 @@ using namespace mireg;
 
 namespace {
 
-__device__ __forceinline__ float ldf(const float* p) { return *p; }
-__device__ __forceinline__ float ldf(const __bf16* p) { return (float)*p; }
-__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
-__device__ __forceinline__ void stf(__bf16* p, float v) { *p = (__bf16)v; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GPTR(T, p) (reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p)))
+#else
+#define GPTR(T, p) (reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p)))
+#endif
 
-// ----------------------------------------------------------------------------------------------
-// weight pack: dst[row][(ty*ntx+tx)*Cpad + c] = W[co][ci][ky0+sy*ty][kx0+sx*tx]   (0 in the pad)
-//   kind 0 (FWD)  : row = co, c = ci         kind 1 (DGRAD): row = ci, c = co
-template <typename T>
-__global__ void __launch_bounds__(256) pack_weights_kernel(const mireg_pack_job* __restrict__ jobs) {
-  const mireg_pack_job j = jobs[blockIdx.y];
-  const long total = (long)j.rows * j.ld;
-  T* __restrict__ dst = reinterpret_cast<T*>(j.dst);
-  const int ktaps = j.nty * j.ntx * j.Cpad;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(i / j.ld), k = (int)(i - (long)row * j.ld);
-    float v = 0.f;
-    if (k < ktaps) {
-      const int tap = k / j.Cpad, c = k - tap * j.Cpad;
-      const int ty = tap / j.ntx, tx = tap - ty * j.ntx;
-      const int ky = j.ky0 + j.sy * ty, kx = j.kx0 + j.sx * tx;
-      const int co = j.kind == 0 ? row : c, ci = j.kind == 0 ? c : row;
-      if (co < j.Co && ci < j.Ci && ky < j.kh && kx < j.kw) v = j.src[(((long)co * j.Ci + ci) * j.kh + ky) * j.kw + kx];
+__device__ __forceinline__ float ldf(const float* p) { return *GPTR(const float, p); }
+__device__ __forceinline__ float ldf(const __bf16* p) { return (float)*GPTR(const __bf16, p); }
+__device__ __forceinline__ void stf(float* p, float v) { *GPTR(float, p) = v; }
+__device__ __forceinline__ void stf(__bf16* p, float v) { *GPTR(__bf16, p) = (__bf16)v; }
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<__bf16> { static constexpr int N = 8; };
+
+// 16-byte vector load / store of VecOf<T>::N elements <-> float registers
+__device__ __forceinline__ void ldv(const float* p, float (&v)[4]) {
+  const float4 q = *GPTR(const float4, p);
+  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+__device__ __forceinline__ void stv(float* p, const float (&v)[4]) { *GPTR(float4, p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void ldv(const __bf16* p, float (&v)[8]) {
+  const uint4 q = *GPTR(const uint4, p);
+  const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+  const bf2 t = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, t);
+}
+__device__ __forceinline__ void stv(__bf16* p, const float (&v)[8]) {
+  *GPTR(uint4, p) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
+// ==============================================================================================
+// weight layout plumbing.  Per conv weight W[co][ci][tap] (torch layout, tap = ky*kw+kx):
+//   FWD pack   F[co][tap*Cip + ci]                       (wave unit = one co x 64 ci, wave-private LDS)
+//   DGRAD pack D_c[ci][tt*Cop + co] = F[co][tap(tt)*Cip + ci]   (block = 64 co x 64 ci transpose of one tap)
+//   unpack     grad[co][ci][tap] = sum_z slab[z][co][tap*Cip + ci]   (wave unit, reversed FWD pack)
+// Work items are flattened over all jobs: job j owns units [unit0, unit0 + nunits).
+// ==============================================================================================
+constexpr int kPackMaxTaps = 25;       // wave-private LDS path; larger kernels (7x7 stems) use the scalar path
+
+__device__ __forceinline__ int find_job(const mireg_pack_job* jobs, int njobs, int unit) {
+  int lo = 0;
+  for (int i = 1; i < njobs; ++i) if (GPTR(const mireg_pack_job, jobs + i)->unit0 <= unit) lo = i;
+  return lo;
+}
+
+__device__ __forceinline__ int find_job_d(const mireg_pack_job* jobs, int njobs, int unit) {
+  int lo = 0;
+  for (int i = 1; i < njobs; ++i) if (GPTR(const mireg_pack_job, jobs + i)->dunit0 <= unit) lo = i;
+  return lo;
+}
+
+// MODE 0: FWD pack (src = torch weight fp32, dst = F in T).  MODE 1: unpack (src = slab fp32, dst = torch grad fp32)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) pack_fwd_kernel(const mireg_pack_job* __restrict__ jobs, int njobs, int total_units) {
+  __shared__ float lds[4][64 * kPackMaxTaps];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* tile = lds[wid];
+  for (int unit = blockIdx.x * 4 + wid; unit < total_units; unit += gridDim.x * 4) {
+    const mireg_pack_job j = *GPTR(const mireg_pack_job, jobs + find_job(jobs, njobs, unit));
+    const int taps = j.kh * j.kw, tp = taps | 1;
+    const int C = MODE == 0 ? j.Cpad : j.Ci;            // ci extent walked by this mode
+    const int chunks = (C + 63) / 64;
+    const int u = unit - j.unit0;
+    const int co = u / chunks, ci0 = (u - co * chunks) * 64;
+    const int nci = max(0, min(64, j.Ci - ci0));        // real channels in this chunk
+    const int run = nci * taps;
+    const unsigned magic = (unsigned)((0x100000000ull + taps - 1) / taps);
+    if (taps > kPackMaxTaps) {                           // rare (7x7 stem with 1-2 input channels): direct gather
+      if (MODE == 0) {
+        for (int e = lane; e < 64 * taps; e += 64) {
+          const int tap = e / 64, ci = e - tap * 64;
+          if (ci0 + ci < j.Cpad)
+            stf(reinterpret_cast<T*>(j.dst) + (long)co * j.ld + (long)tap * j.Cpad + ci0 + ci,
+                ci < nci ? ldf(j.src + ((long)co * j.Ci + ci0 + ci) * taps + tap) : 0.f);
+        }
+      } else {
+        for (int r = lane; r < run; r += 64) {            // r = ci*taps + tap: every lane busy, z-loads pipelined
+          const int ci = (int)__umulhi((unsigned)r, magic), tap = r - ci * taps;
+          const float* sp = j.src + (long)co * j.ld + (long)tap * j.Cpad + ci0 + ci;
+          float v = 0.f;
+#pragma unroll 8
+          for (int z = 0; z < j.nsplit; ++z) v += ldf(sp + (long)z * j.Co * j.ld);
+          float* d = reinterpret_cast<float*>(j.dst) + ((long)co * j.Ci + ci0) * taps + r;
+          stf(d, j.accumulate ? ldf(d) + v : v);
+        }
+      }
+      continue;
     }
-    stf(dst + i, v);
+    if (MODE == 0) {
+      const float* src = j.src + ((long)co * j.Ci + ci0) * taps;
+#pragma unroll 4
+      for (int r = lane; r < run; r += 64) {
+        const int ci = (int)__umulhi((unsigned)r, magic);
+        tile[ci * tp + (r - ci * taps)] = ldf(src + r);
+      }
+      T* dst = reinterpret_cast<T*>(j.dst) + (long)co * j.ld + ci0 + lane;
+      if (ci0 + lane < j.Cpad) {
+#pragma unroll 4
+        for (int tap = 0; tap < taps; ++tap) stf(dst + (long)tap * j.Cpad, lane < nci ? tile[lane * tp + tap] : 0.f);
+      }
+    } else {
+      if (lane < nci) {
+        const float* sp = j.src + (long)co * j.ld + ci0 + lane;
+        const long slab_sz = (long)j.Co * j.ld;
+#pragma unroll 4
+        for (int tap = 0; tap < taps; ++tap) {
+          float v = 0.f;
+#pragma unroll 4
+          for (int z = 0; z < j.nsplit; ++z) v += ldf(sp + (long)tap * j.Cpad + z * slab_sz);
+          tile[lane * tp + tap] = v;
+        }
+      }
+      float* d = reinterpret_cast<float*>(j.dst) + ((long)co * j.Ci + ci0) * taps;
+#pragma unroll 4
+      for (int r = lane; r < run; r += 64) {
+        const int ci = (int)__umulhi((unsigned)r, magic);
+        const float v = tile[ci * tp + (r - ci * taps)];
+        stf(d + r, j.accumulate ? ldf(d + r) + v : v);
+      }
+    }
   }
 }
 
-// gradient unpack: grad[co][ci][ky][kx] = sum_z slab[z][co][(ky*kw+kx)*Cpad + ci]   (torch layout, fp32)
-__global__ void __launch_bounds__(256) unpack_wgrad_kernel(const mireg_pack_job* __restrict__ jobs) {
-  const mireg_pack_job j = jobs[blockIdx.y];   // src = slab, dst = grad, rows = Co, ld = taps*Cpad, sy = nsplit
-  const long total = (long)j.Co * j.Ci * j.kh * j.kw;
-  const long slab_sz = (long)j.Co * j.ld;
-  float* __restrict__ dst = reinterpret_cast<float*>(j.dst);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int kx = (int)(i % j.kw);
-    const int ky = (int)((i / j.kw) % j.kh);
-    const int ci = (int)((i / ((long)j.kw * j.kh)) % j.Ci);
-    const int co = (int)(i / ((long)j.kw * j.kh * j.Ci));
-    const long s = (long)co * j.ld + (long)(ky * j.kw + kx) * j.Cpad + ci;
-    float v = 0.f;
-    for (int z = 0; z < j.sy; ++z) v += j.src[z * slab_sz + s];
-    dst[i] = j.kind ? dst[i] + v : v;
+// DGRAD packs from the FWD pack: D_c[ci][tt*Cop + co] = F[co][tap*Cip + ci]; block = (64 co x 64 ci) of one (class, tt)
+template <typename T>
+__global__ void __launch_bounds__(256) pack_dgrad_kernel(const mireg_pack_job* __restrict__ jobs, int njobs) {
+  __shared__ T tile[64][64 + 2];
+  const mireg_pack_job j = *GPTR(const mireg_pack_job, jobs + find_job_d(jobs, njobs, blockIdx.x));
+  const int co_t = (j.Cop + 63) / 64, ci_t = (j.Ci + 63) / 64;
+  int u = blockIdx.x - j.dunit0, c = 0;
+  for (; c < j.nclass; ++c) {                           // which class / tap / tile
+    const int n = j.cls[c].nty * j.cls[c].ntx * co_t * ci_t;
+    if (u < n) break;
+    u -= n;
+  }
+  const mireg_pack_class k = j.cls[c];
+  const int tt = u / (co_t * ci_t), rem = u - tt * (co_t * ci_t);
+  const int co0 = (rem / ci_t) * 64, ci0 = (rem % ci_t) * 64;
+  const int ty = tt / k.ntx, tx = tt - ty * k.ntx;
+  const int tap = (k.ky0 + j.stride * ty) * j.kw + k.kx0 + j.stride * tx;
+  const int lane = threadIdx.x & 63, wr = threadIdx.x >> 6;
+  const T* F = reinterpret_cast<const T*>(j.dst);
+  for (int r = wr; r < 64; r += 4) {                    // rows = co, lanes = ci
+    const int co = co0 + r, ci = ci0 + lane;
+    T v = (T)0.f;
+    if (co < j.Co && ci < j.Cpad) v = *GPTR(const T, F + (long)co * j.ld + (long)tap * j.Cpad + ci);
+    tile[r][lane] = v;
+  }
+  __syncthreads();
+  T* D = reinterpret_cast<T*>(k.dst);
+  for (int r = wr; r < 64; r += 4) {                    // rows = ci, lanes = co
+    const int ci = ci0 + r, co = co0 + lane;
+    if (ci < j.Ci && co < j.Cop) *GPTR(T, D + (long)ci * k.ld + (long)tt * j.Cop + co) = tile[lane][r];
   }
 }
 
-// ----------------------------------------------------------------------------------------------
-// BatchNorm (train mode = batch statistics over all rows)
+// ==============================================================================================
+// BatchNorm (train mode = batch statistics over all rows); vector path: C % VEC == 0, 16-B aligned views
+// ==============================================================================================
+// stage 1: partial[blk][2*C]:  FWD {sum y, sum y^2}   BWD {sum dz, sum dz*xhat}, dz = da * lrelu'(y*scale+shift)
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(256)
-bn_reduce_kernel(const T* __restrict__ y, long ld_y, const T* __restrict__ da, long ld_da, const float* __restrict__ ss,
-                 double* __restrict__ sums, long M, int C, float slope) {
-  // FWD: sums[c] += y, sums[C+c] += y^2.   BWD: dz = da*lrelu'(z); sums[c] += dz, sums[C+c] += dz*xhat
-  constexpr int VEC = 4;
-  __shared__ float red[2][256][VEC];
-  const int cpr = (C + VEC - 1) / VEC;                 // channel groups per row
-  const int tx = threadIdx.x % min(cpr, 256), tyy = threadIdx.x / min(cpr, 256);
-  const int rpp = 256 / min(cpr, 256);                 // rows per pass
-  const float* scale = ss, *shift = ss + C, *mean = ss + 2 * C, *rstd = ss + 3 * C;
-  for (int cbase = 0; cbase < cpr; cbase += 256) {   // uniform trip count: the loop body holds barriers
-    const int cg = cbase + tx;
-    float a0[VEC] = {0, 0, 0, 0}, a1[VEC] = {0, 0, 0, 0};
-    float sc[VEC], sh[VEC], mu[VEC], rs[VEC];
+bn_partial_kernel(const T* __restrict__ y, long ld_y, const T* __restrict__ da, long ld_da, const float* __restrict__ ss,
+                  float* __restrict__ partial, long M, int C, float slope) {
+  constexpr int V = VecOf<T>::N;
+  __shared__ float red[256][2 * V + 1];
+  const int cpr = C / V;                                // 16-B chunks per row (<= 256)
+  const int rpp = 256 / cpr;                            // rows per pass
+  const int tx = threadIdx.x % cpr, ty = threadIdx.x / cpr;
+  float a0[V], a1[V], sc[V], sh[V], mu[V], rs[V];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const int c = cg * VEC + v;
-      const bool ok = BWD && c < C;
-      sc[v] = ok ? scale[c] : 0.f; sh[v] = ok ? shift[c] : 0.f; mu[v] = ok ? mean[c] : 0.f; rs[v] = ok ? rstd[c] : 0.f;
-    }
-    if (tyy < rpp && cg < cpr) {
-      for (long m = (long)blockIdx.x * rpp + tyy; m < M; m += (long)gridDim.x * rpp) {
+  for (int v = 0; v < V; ++v) {
+    a0[v] = a1[v] = 0.f;
+    if (BWD) { const int c = tx * V + v; sc[v] = ss[c]; sh[v] = ss[C + c]; mu[v] = ss[2 * C + c]; rs[v] = ss[3 * C + c]; }
+  }
+  if (ty < rpp) {
+    for (long m = (long)blockIdx.x * rpp + ty; m < M; m += (long)gridDim.x * rpp) {
+      float yv[V];
+      ldv(y + m * ld_y + tx * V, yv);
+      if (!BWD) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const int c = cg * VEC + v;
-          if (c >= C) continue;
-          const float yv = ldf(y + m * ld_y + c);
-          if (!BWD) { a0[v] += yv; a1[v] += yv * yv; }
-          else {
-            const float z = yv * sc[v] + sh[v];
-            const float dz = ldf(da + m * ld_da + c) * (z > 0.f ? 1.f : slope);
-            a0[v] += dz; a1[v] += dz * ((yv - mu[v]) * rs[v]);
-          }
+        for (int v = 0; v < V; ++v) { a0[v] += yv[v]; a1[v] += yv[v] * yv[v]; }
+      } else {
+        float g[V];
+        ldv(da + m * ld_da + tx * V, g);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const float z = yv[v] * sc[v] + sh[v];
+          const float dz = g[v] * (z > 0.f ? 1.f : slope);
+          a0[v] += dz; a1[v] += dz * ((yv[v] - mu[v]) * rs[v]);
         }
       }
     }
+  }
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { red[0][threadIdx.x][v] = a0[v]; red[1][threadIdx.x][v] = a1[v]; }
-    __syncthreads();
-    if (tyy == 0 && cpr <= 256) {
-      const int w = min(cpr, 256);
-      for (int rr = 1; rr < rpp; ++rr)
+  for (int v = 0; v < V; ++v) { red[threadIdx.x][v] = a0[v]; red[threadIdx.x][V + v] = a1[v]; }
+  __syncthreads();
+  if (ty == 0) {
+    for (int r = 1; r < rpp; ++r)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) { a0[v] += red[0][rr * w + tx][v]; a1[v] += red[1][rr * w + tx][v]; }
-    }
-    if (tyy == 0 && cg < cpr) {
+      for (int v = 0; v < V; ++v) { a0[v] += red[r * cpr + tx][v]; a1[v] += red[r * cpr + tx][V + v]; }
+    float* dst = partial + (long)blockIdx.x * 2 * C;
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const int c = cg * VEC + v;
-        if (c < C) { atomicAdd(&sums[c], (double)a0[v]); atomicAdd(&sums[C + c], (double)a1[v]); }
-      }
-    }
-    __syncthreads();
+    for (int v = 0; v < V; ++v) { dst[tx * V + v] = a0[v]; dst[C + tx * V + v] = a1[v]; }
   }
 }
 
-// ss = [scale | shift | mean | rstd] (4*C floats)
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, long M, int C, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* running_mean, float* running_var,
-                                   float momentum, float eps, int training, float* __restrict__ ss) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// scalar fallback (any C): one atomic-free pass per block over a strided row set
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256)
+bn_partial_scalar_kernel(const T* __restrict__ y, long ld_y, const T* __restrict__ da, long ld_da, const float* __restrict__ ss,
+                         float* __restrict__ partial, long M, int C, float slope) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f;
+    for (long m = blockIdx.x; m < M; m += gridDim.x) {
+      const float yv = ldf(y + m * ld_y + c);
+      if (!BWD) { a0 += yv; a1 += yv * yv; }
+      else {
+        const float z = yv * ss[c] + ss[C + c];
+        const float dz = ldf(da + m * ld_da + c) * (z > 0.f ? 1.f : slope);
+        a0 += dz; a1 += dz * ((yv - ss[2 * C + c]) * ss[3 * C + c]);
+      }
+    }
+    partial[(long)blockIdx.x * 2 * C + c] = a0;
+    partial[(long)blockIdx.x * 2 * C + C + c] = a1;
+  }
+}
+
+// stage 2: block = 32 channels x 8 partial-row lanes; sums the partial rows in float64
+__device__ __forceinline__ void sum_partials(const float* __restrict__ partial, int nblk, int C, int c, int rl,
+                                             double (*sh)[32][2], double& s0, double& s1) {
+  s0 = 0; s1 = 0;
+  if (c < C)
+    for (int b = rl; b < nblk; b += 8) { s0 += ldf(partial + (long)b * 2 * C + c); s1 += ldf(partial + (long)b * 2 * C + C + c); }
+  sh[rl][threadIdx.x & 31][0] = s0; sh[rl][threadIdx.x & 31][1] = s1;
+  __syncthreads();
+  if (rl == 0)
+    for (int r = 1; r < 8; ++r) { s0 += sh[r][threadIdx.x & 31][0]; s1 += sh[r][threadIdx.x & 31][1]; }
+}
+
+// forward: -> ss = [scale | shift | mean | rstd], running stats (momentum, unbiased variance)
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+                   int training, float* __restrict__ ss) {
+  __shared__ double sh[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  double s0 = 0, s1 = 0;
+  if (training) sum_partials(partial, nblk, C, c, rl, sh, s0, s1);
+  if (rl != 0 || c >= C) return;
   float mean, var;
   if (training) {
-    const double mu = sums[c] / (double)M;
-    double vr = sums[C + c] / (double)M - mu * mu;
+    const double mu = s0 / (double)M;
+    double vr = s1 / (double)M - mu * mu;
     if (vr < 0) vr = 0;
     mean = (float)mu; var = (float)vr;
     if (running_mean) {
@@ -139,62 +285,79 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, long M, int 
   ss[c] = sc; ss[C + c] = beta[c] - mean * sc; ss[2 * C + c] = mean; ss[3 * C + c] = rstd;
 }
 
-// out = lrelu(y*scale + shift)
-template <typename T>
+// backward: red[c] = sum dz / M, red[C+c] = sum dz*xhat / M; dgamma, dbeta
 __global__ void __launch_bounds__(256)
-bn_apply_kernel(const T* __restrict__ y, long ld_y, T* __restrict__ out, long ld_o, const float* __restrict__ ss,
-                long M, int C, float slope) {
-  const long total = M * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / C; const int c = (int)(i - m * C);
-    const float z = ldf(y + m * ld_y + c) * ss[c] + ss[C + c];
-    stf(out + m * ld_o + c, z > 0.f ? z : z * slope);
+bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C, float* __restrict__ red,
+                       float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_param_grads) {
+  __shared__ double sh[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  double s0, s1;
+  sum_partials(partial, nblk, C, c, rl, sh, s0, s1);
+  if (rl != 0 || c >= C) return;
+  red[c] = (float)(s0 / (double)M); red[C + c] = (float)(s1 / (double)M);
+  if (dgamma) {
+    dgamma[c] = (acc_param_grads ? dgamma[c] : 0.f) + (float)s1;
+    dbeta[c] = (acc_param_grads ? dbeta[c] : 0.f) + (float)s0;
   }
 }
 
-// dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat));  also dgamma = sum dz*xhat, dbeta = sum dz (block 0)
-template <typename T>
+// out = lrelu(y*scale + shift)            (MODE 0)
+// dy  = scale*(dz - red0 - xhat*red1)     (MODE 1; dz as above)
+template <typename T, int MODE, bool VECT>
 __global__ void __launch_bounds__(256)
-bn_bwd_apply_kernel(const T* __restrict__ y, long ld_y, const T* __restrict__ da, long ld_da, T* __restrict__ dy, long ld_dy,
-                    const float* __restrict__ ss, const double* __restrict__ sums, float* __restrict__ dgamma,
-                    float* __restrict__ dbeta, int acc_param_grads, long M, int C, float slope) {
-  const long total = M * C;
-  const float invM = 1.f / (float)M;
+bn_elementwise_kernel(const T* __restrict__ y, long ld_y, const T* __restrict__ da, long ld_da, T* __restrict__ out, long ld_o,
+                      const float* __restrict__ ss, const float* __restrict__ red, long M, int C, float slope) {
+  constexpr int V = VECT ? VecOf<T>::N : 1;
+  const int cpr = C / V;
+  const long total = M * cpr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / C; const int c = (int)(i - m * C);
-    const float yv = ldf(y + m * ld_y + c);
-    const float z = yv * ss[c] + ss[C + c];
-    const float dz = ldf(da + m * ld_da + c) * (z > 0.f ? 1.f : slope);
-    const float xh = (yv - ss[2 * C + c]) * ss[3 * C + c];
-    stf(dy + m * ld_dy + c, ss[c] * (dz - (float)sums[c] * invM - xh * (float)sums[C + c] * invM));
-  }
-  if (blockIdx.x == 0 && dgamma) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      dgamma[c] = (acc_param_grads ? dgamma[c] : 0.f) + (float)sums[C + c];
-      dbeta[c] = (acc_param_grads ? dbeta[c] : 0.f) + (float)sums[c];
+    const long m = i / cpr;
+    const int c0 = (int)(i - m * cpr) * V;
+    float yv[V], g[V], o[V];
+    if constexpr (VECT) { ldv(y + m * ld_y + c0, yv); if (MODE == 1) ldv(da + m * ld_da + c0, g); }
+    else { yv[0] = ldf(y + m * ld_y + c0); if (MODE == 1) g[0] = ldf(da + m * ld_da + c0); }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c = c0 + v;
+      const float z = yv[v] * ss[c] + ss[C + c];
+      if (MODE == 0) o[v] = z > 0.f ? z : z * slope;
+      else {
+        const float dz = g[v] * (z > 0.f ? 1.f : slope);
+        const float xh = (yv[v] - ss[2 * C + c]) * ss[3 * C + c];
+        o[v] = ss[c] * (dz - red[c] - xh * red[C + c]);
+      }
     }
+    if constexpr (VECT) stv(out + m * ld_o + c0, o); else stf(out + m * ld_o + c0, o[0]);
   }
 }
 
 // in-place LeakyReLU backward through a stored activation: g *= (a > 0 ? 1 : slope)
-template <typename T>
+template <typename T, bool VECT>
 __global__ void __launch_bounds__(256)
 lrelu_bwd_kernel(T* __restrict__ g, long ld_g, const T* __restrict__ a, long ld_a, long M, int C, float slope) {
-  const long total = M * C;
+  constexpr int V = VECT ? VecOf<T>::N : 1;
+  const int cpr = C / V;
+  const long total = M * cpr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / C; const int c = (int)(i - m * C);
-    if (!(ldf(a + m * ld_a + c) > 0.f)) stf(g + m * ld_g + c, ldf(g + m * ld_g + c) * slope);
+    const long m = i / cpr;
+    const int c0 = (int)(i - m * cpr) * V;
+    float gv[V], av[V];
+    if constexpr (VECT) { ldv(g + m * ld_g + c0, gv); ldv(a + m * ld_a + c0, av); }
+    else { gv[0] = ldf(g + m * ld_g + c0); av[0] = ldf(a + m * ld_a + c0); }
+#pragma unroll
+    for (int v = 0; v < V; ++v) gv[v] = av[v] > 0.f ? gv[v] : gv[v] * slope;
+    if constexpr (VECT) stv(g + m * ld_g + c0, gv); else stf(g + m * ld_g + c0, gv[0]);
   }
 }
 
-// dst(T)[m][c] = (beta ? dst : 0) + alpha * src(f32)[m][c]     and the reverse direction
+// dst(T)[m][c] = beta*dst + alpha*src(f32)[m][c]     and the reverse direction
 template <typename T>
 __global__ void __launch_bounds__(256)
 cast_from_f32_kernel(T* __restrict__ dst, long ld_d, const float* __restrict__ src, long ld_s, long M, int C, float alpha, float beta) {
   const long total = M * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / C; const int c = (int)(i - m * C);
-    const float v = alpha * src[m * ld_s + c] + (beta != 0.f ? beta * ldf(dst + m * ld_d + c) : 0.f);
+    const float v = alpha * ldf(src + m * ld_s + c) + (beta != 0.f ? beta * ldf(dst + m * ld_d + c) : 0.f);
     stf(dst + m * ld_d + c, v);
   }
 }
@@ -204,7 +367,7 @@ cast_to_f32_kernel(float* __restrict__ dst, long ld_d, const T* __restrict__ src
   const long total = M * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / C; const int c = (int)(i - m * C);
-    dst[m * ld_d + c] = alpha * ldf(src + m * ld_s + c) + (beta != 0.f ? beta * dst[m * ld_d + c] : 0.f);
+    stf(dst + m * ld_d + c, alpha * ldf(src + m * ld_s + c) + (beta != 0.f ? beta * ldf(dst + m * ld_d + c) : 0.f));
   }
 }
 
@@ -215,7 +378,7 @@ nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, i
   const long total = (long)B * HW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long b = i / HW, pix = i - b * HW;
-    for (int c = 0; c < nc; ++c) stf(dst + i * ld + c, src[(b * Ctot + c0 + c) * HW + pix]);
+    for (int c = 0; c < nc; ++c) stf(dst + i * ld + c, ldf(src + (b * Ctot + c0 + c) * HW + pix));
   }
 }
 
@@ -234,104 +397,143 @@ colsum_kernel(const T* __restrict__ g, long ld, long M, int C, float* __restrict
 }
 
 // fused multi-tensor Adam (torch.optim.Adam semantics, no weight decay / amsgrad); step lives on device so
-// the launch is hipGraph-replayable.
+// the launch is hipGraph-replayable.  float4 streams: 28 B of traffic per parameter.
 __global__ void adam_tick_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
 
 __global__ void __launch_bounds__(256)
 adam_kernel(const mireg_adam_job* __restrict__ jobs, const int* __restrict__ step, float lr, float b1, float b2, float eps,
             float grad_scale) {
-  const mireg_adam_job j = jobs[blockIdx.y];
+  const mireg_adam_job j = *GPTR(const mireg_adam_job, jobs + blockIdx.y);
   const float t = (float)*step;
   const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
   const float step_size = lr / bc1;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < j.n; i += (long)gridDim.x * blockDim.x) {
-    const float g = j.g[i] * grad_scale;
-    const float m = b1 * j.m[i] + (1.f - b1) * g;
-    const float v = b2 * j.v[i] + (1.f - b2) * g * g;
-    j.m[i] = m; j.v[i] = v;
-    j.p[i] -= step_size * (m / (sqrtf(v) / bc2s + eps));
+  const long n4 = (((uintptr_t)j.p | (uintptr_t)j.g | (uintptr_t)j.m | (uintptr_t)j.v) & 15) ? 0 : (j.n >> 2);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float p[4], g[4], m[4], v[4];
+    ldv(j.p + 4 * i, p); ldv(j.g + 4 * i, g); ldv(j.m + 4 * i, m); ldv(j.v + 4 * i, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = g[e] * grad_scale;
+      m[e] = b1 * m[e] + (1.f - b1) * gg;
+      v[e] = b2 * v[e] + (1.f - b2) * gg * gg;
+      p[e] -= step_size * (m[e] / (sqrtf(v[e]) / bc2s + eps));
+    }
+    stv(j.p + 4 * i, p); stv(j.m + 4 * i, m); stv(j.v + 4 * i, v);
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < j.n; i += (long)gridDim.x * blockDim.x) {
+    const float g = ldf(j.g + i) * grad_scale;
+    const float m = b1 * ldf(j.m + i) + (1.f - b1) * g;
+    const float v = b2 * ldf(j.v + i) + (1.f - b2) * g * g;
+    stf(j.m + i, m); stf(j.v + i, v);
+    stf(j.p + i, ldf(j.p + i) - step_size * (m / (sqrtf(v) / bc2s + eps)));
   }
 }
 
-inline int grid1(long work, int cap = 2048) {
+inline int grid1(long work, int cap = 4096) {
   long g = (work + 255) / 256;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
-#define DISPATCH_T(dtype, KERNEL, GRID, ...)                                                                      \
-  do {                                                                                                              \
-    if ((dtype) == MIREG_DTYPE_BF16) hipLaunchKernelGGL((KERNEL<__bf16>), GRID, dim3(256), 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<float>), GRID, dim3(256), 0, stream, __VA_ARGS__);                              \
-  } while (0)
+inline bool vec_ok(int dtype, int C, std::initializer_list<long> lds, std::initializer_list<const void*> ptrs) {
+  const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
+  if (C % V || C / V > 256) return false;
+  for (long l : lds) if (l % V) return false;
+  for (const void* p : ptrs) if ((uintptr_t)p % 16) return false;
+  return true;
+}
+inline int bn_blocks(long M, int C, int dtype, bool vec) {
+  if (!vec) { long g = M < 256 ? M : 256; return (int)(g < 1 ? 1 : g); }
+  const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
+  const int rpp = 256 / (C / V);
+  long g = (M + (long)rpp * 8 - 1) / ((long)rpp * 8);
+  return (int)(g < 1 ? 1 : (g > MIREG_BN_MAX_BLOCKS ? MIREG_BN_MAX_BLOCKS : g));
+}
+
+template <typename T, bool BWD>
+void launch_partial(const void* y, long ld_y, const void* da, long ld_da, const float* ss, float* partial, long M, int C,
+                    float slope, int nblk, bool vec, hipStream_t stream) {
+  if (vec) hipLaunchKernelGGL((bn_partial_kernel<T, BWD>), dim3(nblk), dim3(256), 0, stream, (const T*)y, ld_y, (const T*)da, ld_da, ss, partial, M, C, slope);
+  else hipLaunchKernelGGL((bn_partial_scalar_kernel<T, BWD>), dim3(nblk), dim3(256), 0, stream, (const T*)y, ld_y, (const T*)da, ld_da, ss, partial, M, C, slope);
+}
+template <typename T, int MODE>
+void launch_elem(const void* y, long ld_y, const void* da, long ld_da, void* out, long ld_o, const float* ss, const float* red,
+                 long M, int C, float slope, bool vec, hipStream_t stream) {
+  const int V = vec ? VecOf<T>::N : 1;
+  const dim3 g(grid1(M * (C / V)));
+  if (vec) hipLaunchKernelGGL((bn_elementwise_kernel<T, MODE, true>), g, dim3(256), 0, stream, (const T*)y, ld_y, (const T*)da, ld_da, (T*)out, ld_o, ss, red, M, C, slope);
+  else hipLaunchKernelGGL((bn_elementwise_kernel<T, MODE, false>), g, dim3(256), 0, stream, (const T*)y, ld_y, (const T*)da, ld_da, (T*)out, ld_o, ss, red, M, C, slope);
+}
 
 }  // namespace
 
 extern "C" {
 
-int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int dtype, hipStream_t stream) {
-  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && (dtype == MIREG_DTYPE_F32 || dtype == MIREG_DTYPE_BF16));
-  if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((pack_weights_kernel<__bf16>), dim3(64, njobs), dim3(256), 0, stream, jobs_dev);
-  else hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(64, njobs), dim3(256), 0, stream, jobs_dev);
-  MIREG_LAUNCH_RET();
-}
-
-int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, hipStream_t stream) {
-  MIREG_CHECK_ARG(jobs_dev && njobs > 0);
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(64, njobs), dim3(256), 0, stream, jobs_dev);
-  MIREG_LAUNCH_RET();
-}
-
-int mireg_bn_stats(const void* y, long ld_y, long M, int C, double* sums, int dtype, hipStream_t stream) {
-  MIREG_CHECK_ARG(y && sums && M > 0 && C > 0 && C <= 4096);
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream) != hipSuccess) return MIREG_ERR_LAUNCH;
-  const int cpr = (C + 3) / 4, rpp = 256 / (cpr < 256 ? cpr : 256);
-  long g = (M + rpp * 8 - 1) / (rpp * 8);
-  if (g > 1024) g = 1024;
-  if (dtype == MIREG_DTYPE_BF16)
-    hipLaunchKernelGGL((bn_reduce_kernel<__bf16, false>), dim3((unsigned)g), dim3(256), 0, stream, (const __bf16*)y, ld_y, (const __bf16*)nullptr, 0L, (const float*)nullptr, sums, M, C, 0.f);
-  else
-    hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)y, ld_y, (const float*)nullptr, 0L, (const float*)nullptr, sums, M, C, 0.f);
-  MIREG_LAUNCH_RET();
-}
-
-int mireg_bn_finalize(const double* sums, long M, int C, const float* gamma, const float* beta, float* running_mean,
-                      float* running_var, float momentum, float eps, int training, float* ss, hipStream_t stream) {
-  MIREG_CHECK_ARG(gamma && beta && ss && M > 0 && C > 0 && (training ? sums != nullptr : (running_mean && running_var)));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, M, C, gamma, beta, running_mean,
-                     running_var, momentum, eps, training, ss);
-  MIREG_LAUNCH_RET();
-}
-
-int mireg_bn_apply(const void* y, long ld_y, void* out, long ld_o, const float* ss, long M, int C, float slope, int dtype,
-                   hipStream_t stream) {
-  MIREG_CHECK_ARG(y && out && ss && M > 0 && C > 0);
-  if (dtype == MIREG_DTYPE_BF16)
-    hipLaunchKernelGGL((bn_apply_kernel<__bf16>), dim3(grid1(M * C)), dim3(256), 0, stream, (const __bf16*)y, ld_y, (__bf16*)out, ld_o, ss, M, C, slope);
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid1(M * C)), dim3(256), 0, stream, (const float*)y, ld_y, (float*)out, ld_o, ss, M, C, slope);
-  MIREG_LAUNCH_RET();
-}
-
-int mireg_bn_bwd(const void* y, long ld_y, const void* da, long ld_da, void* dy, long ld_dy, const float* ss, double* sums,
-                 float* dgamma, float* dbeta, int acc_param_grads, long M, int C, float slope, int dtype, hipStream_t stream) {
-  MIREG_CHECK_ARG(y && da && dy && ss && sums && M > 0 && C > 0 && C <= 4096);
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream) != hipSuccess) return MIREG_ERR_LAUNCH;
-  const int cpr = (C + 3) / 4, rpp = 256 / (cpr < 256 ? cpr : 256);
-  long g = (M + rpp * 8 - 1) / (rpp * 8);
-  if (g > 1024) g = 1024;
+int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int total_units, int total_dgrad_units, int dtype,
+                       hipStream_t stream) {
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units > 0 && total_dgrad_units >= 0 &&
+                  (dtype == MIREG_DTYPE_F32 || dtype == MIREG_DTYPE_BF16));
+  const int g = total_units / 4 + 1 < 2048 ? total_units / 4 + 1 : 2048;
   if (dtype == MIREG_DTYPE_BF16) {
-    hipLaunchKernelGGL((bn_reduce_kernel<__bf16, true>), dim3((unsigned)g), dim3(256), 0, stream, (const __bf16*)y, ld_y, (const __bf16*)da, ld_da, ss, sums, M, C, slope);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<__bf16>), dim3(grid1(M * C)), dim3(256), 0, stream, (const __bf16*)y, ld_y, (const __bf16*)da, ld_da, (__bf16*)dy, ld_dy, ss, sums, dgamma, dbeta, acc_param_grads, M, C, slope);
+    hipLaunchKernelGGL((pack_fwd_kernel<__bf16, 0>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
+    if (total_dgrad_units) hipLaunchKernelGGL((pack_dgrad_kernel<__bf16>), dim3(total_dgrad_units), dim3(256), 0, stream, jobs_dev, njobs);
   } else {
-    hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)y, ld_y, (const float*)da, ld_da, ss, sums, M, C, slope);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid1(M * C)), dim3(256), 0, stream, (const float*)y, ld_y, (const float*)da, ld_da, (float*)dy, ld_dy, ss, sums, dgamma, dbeta, acc_param_grads, M, C, slope);
+    hipLaunchKernelGGL((pack_fwd_kernel<float, 0>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
+    if (total_dgrad_units) hipLaunchKernelGGL((pack_dgrad_kernel<float>), dim3(total_dgrad_units), dim3(256), 0, stream, jobs_dev, njobs);
   }
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, int total_units, hipStream_t stream) {
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units > 0);
+  const int g = total_units / 4 + 1 < 2048 ? total_units / 4 + 1 : 2048;
+  hipLaunchKernelGGL((pack_fwd_kernel<float, 1>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_bn_forward(const void* y, long ld_y, void* out, long ld_o, long M, int C, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int training, float slope,
+                     float* partial, float* ss, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(y && out && gamma && beta && ss && partial && M > 0 && C > 0 && C <= 4096);
+  MIREG_CHECK_ARG(training || (running_mean && running_var));
+  const bool vec = vec_ok(dtype, C, {ld_y, ld_o}, {y, out});
+  const int nblk = bn_blocks(M, C, dtype, vec);
+  if (training) {
+    if (dtype == MIREG_DTYPE_BF16) launch_partial<__bf16, false>(y, ld_y, nullptr, 0, nullptr, partial, M, C, slope, nblk, vec, stream);
+    else launch_partial<float, false>(y, ld_y, nullptr, 0, nullptr, partial, M, C, slope, nblk, vec, stream);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, partial, nblk, M, C, gamma, beta, running_mean,
+                     running_var, momentum, eps, training, ss);
+  if (dtype == MIREG_DTYPE_BF16) launch_elem<__bf16, 0>(y, ld_y, nullptr, 0, out, ld_o, ss, nullptr, M, C, slope, vec, stream);
+  else launch_elem<float, 0>(y, ld_y, nullptr, 0, out, ld_o, ss, nullptr, M, C, slope, vec, stream);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_bn_backward(const void* y, long ld_y, const void* da, long ld_da, void* dy, long ld_dy, const float* ss,
+                      float* partial, float* red, float* dgamma, float* dbeta, int acc_param_grads, long M, int C,
+                      float slope, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(y && da && dy && ss && partial && red && M > 0 && C > 0 && C <= 4096);
+  const bool vec = vec_ok(dtype, C, {ld_y, ld_da, ld_dy}, {y, da, dy});
+  const int nblk = bn_blocks(M, C, dtype, vec);
+  if (dtype == MIREG_DTYPE_BF16) launch_partial<__bf16, true>(y, ld_y, da, ld_da, ss, partial, M, C, slope, nblk, vec, stream);
+  else launch_partial<float, true>(y, ld_y, da, ld_da, ss, partial, M, C, slope, nblk, vec, stream);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, partial, nblk, M, C, red, dgamma, dbeta,
+                     acc_param_grads);
+  if (dtype == MIREG_DTYPE_BF16) launch_elem<__bf16, 1>(y, ld_y, da, ld_da, dy, ld_dy, ss, red, M, C, slope, vec, stream);
+  else launch_elem<float, 1>(y, ld_y, da, ld_da, dy, ld_dy, ss, red, M, C, slope, vec, stream);
   MIREG_LAUNCH_RET();
 }
 
 int mireg_lrelu_bwd(void* g, long ld_g, const void* a, long ld_a, long M, int C, float slope, int dtype, hipStream_t stream) {
   MIREG_CHECK_ARG(g && a && M > 0 && C > 0);
-  if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((lrelu_bwd_kernel<__bf16>), dim3(grid1(M * C)), dim3(256), 0, stream, (__bf16*)g, ld_g, (const __bf16*)a, ld_a, M, C, slope);
-  else hipLaunchKernelGGL((lrelu_bwd_kernel<float>), dim3(grid1(M * C)), dim3(256), 0, stream, (float*)g, ld_g, (const float*)a, ld_a, M, C, slope);
+  const bool vec = vec_ok(dtype, C, {ld_g, ld_a}, {g, a});
+  const int V = vec ? (dtype == MIREG_DTYPE_BF16 ? 8 : 4) : 1;
+  const dim3 grid(grid1(M * (C / V)));
+  if (dtype == MIREG_DTYPE_BF16) {
+    if (vec) hipLaunchKernelGGL((lrelu_bwd_kernel<__bf16, true>), grid, dim3(256), 0, stream, (__bf16*)g, ld_g, (const __bf16*)a, ld_a, M, C, slope);
+    else hipLaunchKernelGGL((lrelu_bwd_kernel<__bf16, false>), grid, dim3(256), 0, stream, (__bf16*)g, ld_g, (const __bf16*)a, ld_a, M, C, slope);
+  } else {
+    if (vec) hipLaunchKernelGGL((lrelu_bwd_kernel<float, true>), grid, dim3(256), 0, stream, (float*)g, ld_g, (const float*)a, ld_a, M, C, slope);
+    else hipLaunchKernelGGL((lrelu_bwd_kernel<float, false>), grid, dim3(256), 0, stream, (float*)g, ld_g, (const float*)a, ld_a, M, C, slope);
+  }
   MIREG_LAUNCH_RET();
 }
 
@@ -373,7 +575,7 @@ int mireg_adam_step(const mireg_adam_job* jobs_dev, int njobs, int* step_dev, fl
                     float grad_scale, hipStream_t stream) {
   MIREG_CHECK_ARG(jobs_dev && njobs > 0 && step_dev);
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, step_dev);
-  hipLaunchKernelGGL(adam_kernel, dim3(128, njobs), dim3(256), 0, stream, jobs_dev, step_dev, lr, beta1, beta2, eps, grad_scale);
+  hipLaunchKernelGGL(adam_kernel, dim3(njobs == 1 ? 4096 : 256, njobs), dim3(256), 0, stream, jobs_dev, step_dev, lr, beta1, beta2, eps, grad_scale);
   MIREG_LAUNCH_RET();
 }
 

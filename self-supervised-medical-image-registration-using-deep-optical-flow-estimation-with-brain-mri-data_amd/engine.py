@@ -42,11 +42,16 @@ class ConvDesc(ctypes.Structure):
                 ("split_k", ctypes.c_int), ("slab", ctypes.c_void_p)]
 
 
+class PackClass(ctypes.Structure):
+    _fields_ = [("dst", ctypes.c_void_p), ("ld", ctypes.c_long), ("ky0", ctypes.c_int), ("kx0", ctypes.c_int),
+                ("nty", ctypes.c_int), ("ntx", ctypes.c_int)]
+
+
 class PackJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("Co", ctypes.c_int), ("Ci", ctypes.c_int),
-                ("kh", ctypes.c_int), ("kw", ctypes.c_int), ("kind", ctypes.c_int), ("Cpad", ctypes.c_int),
-                ("ky0", ctypes.c_int), ("kx0", ctypes.c_int), ("sy", ctypes.c_int), ("sx", ctypes.c_int),
-                ("nty", ctypes.c_int), ("ntx", ctypes.c_int), ("ld", ctypes.c_long), ("rows", ctypes.c_int)]
+                ("kh", ctypes.c_int), ("kw", ctypes.c_int), ("Cpad", ctypes.c_int), ("Cop", ctypes.c_int),
+                ("ld", ctypes.c_long), ("stride", ctypes.c_int), ("nclass", ctypes.c_int), ("cls", PackClass * 4),
+                ("nsplit", ctypes.c_int), ("accumulate", ctypes.c_int), ("unit0", ctypes.c_int), ("dunit0", ctypes.c_int)]
 
 
 class AdamJob(ctypes.Structure):
@@ -56,6 +61,32 @@ class AdamJob(ctypes.Structure):
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def assign_tiles(jobs: Sequence["PackJob"], unpack: bool) -> Tuple[int, int]:
+    """Fill unit0 / dunit0 of every job; returns (total_units, total_dgrad_units) for the launch."""
+    u = d = 0
+    for j in jobs:
+        c = j.Ci if unpack else j.Cpad
+        j.unit0, j.dunit0 = u, d
+        u += j.Co * ((c + 63) // 64)
+        if not unpack:
+            taps = sum(j.cls[i].nty * j.cls[i].ntx for i in range(j.nclass))
+            d += taps * ((j.Cop + 63) // 64) * ((j.Ci + 63) // 64)
+    return u, d
+
+
+def run_pack(jobs: Sequence["PackJob"], code: int, device) -> None:
+    """One-off pack of a few layers (tests / micro-benches)."""
+    units, dunits = assign_tiles(jobs, False)
+    tab = upload_table(jobs, device)
+    _lib.call("mireg_pack_weights", tab.data_ptr(), len(jobs), units, dunits, code, _stream())
+
+
+def run_unpack(jobs: Sequence["PackJob"], device) -> None:
+    units, _ = assign_tiles(jobs, True)
+    tab = upload_table(jobs, device)
+    _lib.call("mireg_unpack_wgrad", tab.data_ptr(), len(jobs), units, _stream())
 
 
 def upload_table(jobs: Sequence[ctypes.Structure], device) -> torch.Tensor:
@@ -195,20 +226,24 @@ class ConvLayer:
 
     # ---- pack jobs ----------------------------------------------------------------------------
     def pack_jobs(self) -> List[PackJob]:
-        jobs = [PackJob(self.weight.data_ptr(), self.packF.data_ptr(), self.Co, self.Ci, self.kh, self.kw, 0, self.Cip,
-                        0, 0, 1, 1, self.kh, self.kw, self.Kf, self.Co)]
-        for c in self.classes:
-            if c["K"] == 0:
-                continue
-            jobs.append(PackJob(self.weight.data_ptr(), c["pack"].data_ptr(), self.Co, self.Ci, self.kh, self.kw, 1,
-                                self.Cop, c["ky0"], c["kx0"], self.s, self.s, c["nty"], c["ntx"], c["pack"].shape[1],
-                                self.Ci))
-        return jobs
+        j = PackJob()
+        j.src, j.dst = self.weight.data_ptr(), self.packF.data_ptr()
+        j.Co, j.Ci, j.kh, j.kw = self.Co, self.Ci, self.kh, self.kw
+        j.Cpad, j.Cop, j.ld, j.stride = self.Cip, self.Cop, self.Kf, self.s
+        live = [c for c in self.classes if c["K"] > 0]
+        j.nclass = len(live)
+        for i, c in enumerate(live):
+            j.cls[i] = PackClass(c["pack"].data_ptr(), c["pack"].shape[1], c["ky0"], c["kx0"], c["nty"], c["ntx"])
+        return [j]
 
     def unpack_job(self, accumulate: bool = False) -> PackJob:
         assert self.wgrad_slab is not None and self.grad_w is not None
-        return PackJob(self.wgrad_slab.data_ptr(), self.grad_w.data_ptr(), self.Co, self.Ci, self.kh, self.kw,
-                       int(accumulate), self.Cip, 0, 0, self.wgrad_split, 1, self.kh, self.kw, self.Kf, self.Co)
+        j = PackJob()
+        j.src, j.dst = self.wgrad_slab.data_ptr(), self.grad_w.data_ptr()
+        j.Co, j.Ci, j.kh, j.kw = self.Co, self.Ci, self.kh, self.kw
+        j.Cpad, j.Cop, j.ld, j.stride, j.nclass = self.Cip, self.Cop, self.Kf, self.s, 0
+        j.nsplit, j.accumulate = self.wgrad_split, int(accumulate)
+        return j
 
     # ---- launches -----------------------------------------------------------------------------
     def _finish(self, d: ConvDesc, M: int, N: int, K: int, allow_split: bool) -> None:
@@ -295,7 +330,7 @@ class ConvLayer:
         bk = 32 if self.ws.code == DT_BF16 else 16
         tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
         nk = (dy.rows + bk - 1) // bk
-        self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((2 * NUM_CU + tiles - 1) // tiles, max(nk // 2, 1), 128))
+        self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((2 * NUM_CU + tiles - 1) // tiles, max(nk // 2, 1), 32))
         self.wgrad_slab = torch.empty(self.wgrad_split, self.Co, self.Kf, device=self.ws.device, dtype=F32)
         if self.grad_w is None:
             self.grad_w = torch.zeros_like(self.weight, dtype=F32)
@@ -328,31 +363,29 @@ class ConvLayer:
 
 class BatchNormAct:
     """Train/eval BatchNorm2d + LeakyReLU on an NHWC view (reference FlowNetS/util.py:17-30)."""
+    MAX_BLOCKS = 1024
 
     def __init__(self, bn: torch.nn.BatchNorm2d, ws: Workspace, slope: float = 0.1):
         self.bn, self.ws, self.slope = bn, ws, slope
         C = bn.num_features
         self.C = C
-        self.sums = torch.zeros(2 * C, device=ws.device, dtype=torch.float64)
+        self.partial = torch.zeros(self.MAX_BLOCKS * 2 * C, device=ws.device, dtype=F32)
         self.ss = torch.zeros(4 * C, device=ws.device, dtype=F32)
+        self.red = torch.zeros(2 * C, device=ws.device, dtype=F32)
         self.grad_g = torch.zeros(C, device=ws.device, dtype=F32)
         self.grad_b = torch.zeros(C, device=ws.device, dtype=F32)
 
     def forward(self, y: View, out: View, training: bool) -> None:
-        st = _stream()
         bn = self.bn
-        if training:
-            _lib.call("mireg_bn_stats", y.ptr, y.ld, y.rows, self.C, self.sums.data_ptr(), self.ws.code, st)
         mom = bn.momentum if bn.momentum is not None else 0.1
-        _lib.call("mireg_bn_finalize", self.sums.data_ptr(), y.rows, self.C, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(mom), float(bn.eps), int(training),
-                  self.ss.data_ptr(), st)
-        _lib.call("mireg_bn_apply", y.ptr, y.ld, out.ptr, out.ld, self.ss.data_ptr(), y.rows, self.C, self.slope,
-                  self.ws.code, st)
+        _lib.call("mireg_bn_forward", y.ptr, y.ld, out.ptr, out.ld, y.rows, self.C, bn.weight.data_ptr(),
+                  bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(mom), float(bn.eps),
+                  int(training), self.slope, self.partial.data_ptr(), self.ss.data_ptr(), self.ws.code, _stream())
 
     def backward(self, y: View, da: View, dy: View) -> None:
-        _lib.call("mireg_bn_bwd", y.ptr, y.ld, da.ptr, da.ld, dy.ptr, dy.ld, self.ss.data_ptr(), self.sums.data_ptr(),
-                  self.grad_g.data_ptr(), self.grad_b.data_ptr(), 0, y.rows, self.C, self.slope, self.ws.code, _stream())
+        _lib.call("mireg_bn_backward", y.ptr, y.ld, da.ptr, da.ld, dy.ptr, dy.ld, self.ss.data_ptr(),
+                  self.partial.data_ptr(), self.red.data_ptr(), self.grad_g.data_ptr(), self.grad_b.data_ptr(), 0, y.rows,
+                  self.C, self.slope, self.ws.code, _stream())
 
 
 def lrelu_bwd(g: View, a: View, slope: float, ws: Workspace) -> None:

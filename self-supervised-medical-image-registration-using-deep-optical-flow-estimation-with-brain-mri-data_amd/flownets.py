@@ -12,8 +12,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import (DT_BF16, F32, BatchNormAct, ConvLayer, View, Workspace, _stream, cast_from_f32, lrelu_bwd,
-                     nchw_to_view, upload_table)
+from .engine import (DT_BF16, F32, BatchNormAct, ConvLayer, View, Workspace, _stream, assign_tiles, cast_from_f32,
+                     lrelu_bwd, nchw_to_view, upload_table)
 
 ENCODER = [  # name, cin, cout, k, stride   (FlowNetS/FlowNetS.py:17-26)
     ("conv1", 2, 64, 7, 2), ("conv2", 64, 128, 5, 2), ("conv3", 128, 256, 5, 2), ("conv3_1", 256, 256, 3, 1),
@@ -56,14 +56,17 @@ class PredictorEngineBase:
         key = tuple(l.weight.data_ptr() for l in self.layers.values())
         if self._pack_key != key:
             jobs = [j for l in self.layers.values() for j in l.pack_jobs()]
+            self._pack_units, self._pack_dunits = assign_tiles(jobs, False)
             self._pack_table, self._pack_n, self._pack_key = upload_table(jobs, self.ws.device), len(jobs), key
-        _lib.call("mireg_pack_weights", self._pack_table.data_ptr(), self._pack_n, self.ws.code, _stream())
+        _lib.call("mireg_pack_weights", self._pack_table.data_ptr(), self._pack_n, self._pack_units, self._pack_dunits,
+                  self.ws.code, _stream())
 
     def unpack_grads(self) -> None:
         if self._unpack_table is None:
             jobs = [l.unpack_job() for l in self.layers.values() if l.wgrad_slab is not None]
+            self._unpack_units, _ = assign_tiles(jobs, True)
             self._unpack_table, self._unpack_n = upload_table(jobs, self.ws.device), len(jobs)
-        _lib.call("mireg_unpack_wgrad", self._unpack_table.data_ptr(), self._unpack_n, _stream())
+        _lib.call("mireg_unpack_wgrad", self._unpack_table.data_ptr(), self._unpack_n, self._unpack_units, _stream())
 
     def bind_flat_grads(self, params: Sequence[nn.Parameter], flat: torch.Tensor) -> None:
         """Make every gradient buffer a view of `flat` (parameter order), so one RCCL all-reduce / one Adam

@@ -63,10 +63,8 @@ def test_conv_three_forms(case, prec):
     lay = ConvLayer("t", w.to(DEV), b.to(DEV) if has_bias else None, s, p, d, ws)
     import ctypes
     from mireg import _lib
-    from mireg.engine import upload_table, _stream
-    jobs = lay.pack_jobs()
-    tab = upload_table(jobs, DEV)
-    _lib.call("mireg_pack_weights", tab.data_ptr(), len(jobs), ws.code, _stream())
+    from mireg.engine import run_pack, run_unpack
+    run_pack(lay.pack_jobs(), ws.code, DEV)
     xv = _view_from(x.to(DEV), ws)
     Ho, Wo = y_ref.shape[2:]
     yv = ws.new(B, Ho, Wo, cout)
@@ -81,8 +79,7 @@ def test_conv_three_forms(case, prec):
     assert _rel(dxv.nchw().float(), 2 * xr.grad) < tol * 2, "dgrad accumulate"
     # backward-weights
     lay.run_wgrad(xv, gv)
-    utab = upload_table([lay.unpack_job()], DEV)
-    _lib.call("mireg_unpack_wgrad", utab.data_ptr(), 1, _stream())
+    run_unpack([lay.unpack_job()], DEV)
     assert _rel(lay.grad_w, wr.grad) < tol, "wgrad"
     if has_bias:
         lay.run_bias_grad(gv)
@@ -92,8 +89,7 @@ def test_conv_three_forms(case, prec):
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_deconv_forms(prec):
     """ConvTranspose2d(k4,s2,p1) == adjoint conv used backwards (FlowNetS/util.py:49-55)."""
-    from mireg.engine import ConvLayer, Workspace, upload_table, _stream
-    from mireg import _lib
+    from mireg.engine import ConvLayer, Workspace, run_pack, run_unpack
     dt = torch.float32 if prec == "fp32" else torch.bfloat16
     tol = 3e-5 if prec == "fp32" else 3e-2
     ws = Workspace(torch.device(DEV), dt)
@@ -111,9 +107,7 @@ def test_deconv_forms(prec):
             cot = cot.bfloat16().float()
         (y_ref * cot).sum().backward()
         lay = ConvLayer("d", w.to(DEV), bias.to(DEV), 2, 1, 1, ws)
-        jobs = lay.pack_jobs()
-        tab = upload_table(jobs, DEV)
-        _lib.call("mireg_pack_weights", tab.data_ptr(), len(jobs), ws.code, _stream())
+        run_pack(lay.pack_jobs(), ws.code, DEV)
         xv = _view_from(x.to(DEV), ws)
         yv = ws.new(B, 2 * H, 2 * H, cout)
         lay.run_dgrad_form(xv, yv, slope=0.1, bias=True)
@@ -126,8 +120,7 @@ def test_deconv_forms(prec):
         lay.run_fwd_form(gv, dxv, bias=False)
         assert _rel(dxv.nchw().float(), xr.grad) < 2 * tol, "deconv bwd-data"
         lay.run_wgrad(gv, xv)
-        utab = upload_table([lay.unpack_job()], DEV)
-        _lib.call("mireg_unpack_wgrad", utab.data_ptr(), 1, _stream())
+        run_unpack([lay.unpack_job()], DEV)
         assert _rel(lay.grad_w, wr.grad) < 2 * tol, "deconv wgrad"
 
 
