@@ -105,6 +105,8 @@ typedef struct mireg_conv_desc {
   float* y32; long y32_ld;
   const float* bias; float slope; int accumulate; int dtype;
   int split_k; float* slab;
+  long x_bytes, w_bytes;   /* readable bytes from x / w to the end of their allocations (buffer descriptors of the
+                              LDS-DMA tile loads; 0 selects the register-staged kernel) */
 } mireg_conv_desc;
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream);
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);
@@ -165,6 +167,22 @@ typedef struct mireg_adam_job { float* p; const float* g; float* m; float* v; lo
  * (1/world_size after a sum all-reduce). */
 int mireg_adam_step(const mireg_adam_job* jobs_dev, int njobs, int* step_dev, float lr, float beta1, float beta2,
                     float eps, float grad_scale, hipStream_t stream);
+
+
+/* ---- K7/K8: cost volume == external correlation_package.Correlation(pad=md, k=1, md, s1=1, s2) ------- */
+/* call sites: flownet2/networks/FlowNetC.py:31,88 (md 20, s2 2); PWC/models/PWCNet.py:69,200-259 (md 4, s2 1);
+ * same values as FlowNetS/util.py:58-72.  NHWC views; out channel (dy+R)*D+(dx+R), R = md/s2, D = 2R+1;
+ * out = lrelu((1/c_norm) * <f1[y,x,:], f2[y+s2*dy, x+s2*dx, :]>, slope), zeros outside f2.  C = channels
+ * walked (padded to 8 bf16 / 4 fp32 with zeros), c_norm = true channel count of the 1/C factor.
+ * The third-party op has no source in the reference tree: parity unpinned, published definition. */
+int mireg_correlation_fwd(const void* f1, long ld1, const void* f2, long ld2, void* out, long ldo, int B, int H,
+                          int W, int C, int c_norm, int max_displacement, int stride2, float slope, int dtype,
+                          hipStream_t stream);
+/* ---- K10: PWCDCNet.warp, PWC/models/PWCNet.py:143-179 (flow fp32 [pix][ldf], pre-scaled by flow_scale) ---- */
+int mireg_pwc_warp_fwd(const void* x, long ldx, const float* flow, long ldf, float flow_scale, void* out, long ldo,
+                       int B, int H, int W, int C, int dtype, hipStream_t stream);
+/* concat staging for producers that cannot write in place (PWCNet.py:217: cat(corr, c1, up_flow, up_feat)) */
+int mireg_copy_channels(const void* src, long ld_s, void* dst, long ld_d, long M, int C, int dtype, hipStream_t stream);
 
 #ifdef __cplusplus
 }

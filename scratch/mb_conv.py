@@ -18,8 +18,10 @@ x = ws.new(B, H, H, cin); x.buf.normal_()
 Ho = (H + 2 * ((k - 1) // 2) - k) // s + 1
 y = ws.new(B, Ho, Ho, cout); y.buf.normal_()
 dx = ws.new(B, H, H, cin)
+import os
+ABL = int(os.environ.get("ABL", "0"))
 def run():
-    if mode == "fwd": lay.run_fwd_form(x, y)
+    if mode == "fwd": lay.run_fwd_form(x, y, accumulate=ABL)
     elif mode == "dgrad": lay.run_dgrad_form(y, dx)
     else: lay.run_wgrad(x, y)
 for _ in range(3): run()

@@ -1,0 +1,56 @@
+"""Cost-volume and PWC warp ops on the HIP kernels (csrc/correlation.hip).
+
+`Correlation` is the drop-in for the external `correlation_package.Correlation` the reference imports
+(flownet2/networks/FlowNetC.py:8,31; PWC/models/PWCNet.py:13,69): same constructor arguments, NCHW fp32
+in / out.  Only the parameterisation the reference uses is supported (kernel_size=1, stride1=1,
+pad_size == max_displacement, corr_multiply=1); anything else raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import DT_BF16, DT_F32, View, _stream, rup
+
+
+def correlation_views(f1: View, f2: View, out: View, c_norm: int, md: int, s2: int, slope: float, code: int) -> None:
+    """NHWC engine entry: out[..., D*D] = lrelu(corr(f1, f2)); f1/f2 channel extent padded with zeros to 8."""
+    cp = rup(f1.C, 8)
+    assert f1.c0 + cp <= f1.ld and f2.c0 + cp <= f2.ld and (f1.B, f1.H, f1.W) == (f2.B, f2.H, f2.W) == (out.B, out.H, out.W)
+    _lib.call("mireg_correlation_fwd", f1.ptr, f1.ld, f2.ptr, f2.ld, out.ptr, out.ld, f1.B, f1.H, f1.W, cp, c_norm, md, s2,
+              slope, code, _stream())
+
+
+def pwc_warp_views(x: View, flow32: View, scale: float, out: View, code: int) -> None:
+    cp = rup(x.C, 8)
+    assert x.c0 + cp <= x.ld and out.c0 + cp <= out.ld
+    _lib.call("mireg_pwc_warp_fwd", x.ptr, x.ld, flow32.ptr, flow32.ld, float(scale), out.ptr, out.ld, x.B, x.H, x.W, cp,
+              code, _stream())
+
+
+class Correlation(nn.Module):
+    def __init__(self, pad_size=20, kernel_size=1, max_displacement=20, stride1=1, stride2=2, corr_multiply=1):
+        super().__init__()
+        if kernel_size != 1 or stride1 != 1 or pad_size != max_displacement or corr_multiply != 1 or max_displacement % stride2:
+            raise NotImplementedError("mireg.Correlation supports kernel_size=1, stride1=1, pad_size==max_displacement, "
+                                      "corr_multiply=1 (the only parameterisations the reference uses)")
+        self.md, self.s2 = max_displacement, stride2
+
+    def forward(self, in1: torch.Tensor, in2: torch.Tensor) -> torch.Tensor:
+        if not in1.is_cuda:
+            raise RuntimeError("mireg.Correlation runs on the MI355X only; there is no CPU fallback")
+        if in1.requires_grad or in2.requires_grad:
+            if torch.is_grad_enabled():
+                raise NotImplementedError("correlation backward is scheduled after the forward path (DESIGN.md section 9)")
+        B, C, H, W = in1.shape
+        cp = rup(C, 4)
+        a = torch.zeros(B, H, W, cp, device=in1.device, dtype=torch.float32)
+        b = torch.zeros(B, H, W, cp, device=in1.device, dtype=torch.float32)
+        a[..., :C] = in1.detach().permute(0, 2, 3, 1)
+        b[..., :C] = in2.detach().permute(0, 2, 3, 1)
+        D = 2 * (self.md // self.s2) + 1
+        out = torch.empty(B, H, W, D * D, device=in1.device, dtype=torch.float32)
+        _lib.call("mireg_correlation_fwd", a.data_ptr(), cp, b.data_ptr(), cp, out.data_ptr(), D * D, B, H, W, cp, C,
+                  self.md, self.s2, 1.0, DT_F32, _stream())
+        return out.permute(0, 3, 1, 2)

@@ -14,6 +14,7 @@
 // to 80 B so that ds_read_b128 fragment reads are bank-conflict free.
 #include "mireg_common.h"
 #include "../../include/mireg.h"
+#include <stdlib.h>
 
 using namespace mireg;
 
@@ -33,6 +34,14 @@ template <typename T> __device__ __forceinline__ Chunk ldg_chunk(const T* p) {
   return Chunk{{v.x, v.y, v.z, v.w}};
 #else
   return *reinterpret_cast<const Chunk*>(p);
+#endif
+}
+
+__device__ __forceinline__ void stg_u4(void* p, uint4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  *reinterpret_cast<__attribute__((address_space(1))) uint4*>(reinterpret_cast<uintptr_t>(p)) = v;
+#else
+  *reinterpret_cast<uint4*>(p) = v;
 #endif
 }
 
@@ -232,6 +241,333 @@ conv_gemm_kernel(const mireg_conv_desc p) {
   }
 }
 
+
+// =====================================================================================================
+// v2 of the same contraction: LDS-DMA ring.  Tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 16 B per
+// lane, 1 KiB per wave-instruction) into a 4-stage ring, so three K-steps of loads are always in flight behind
+// the MFMAs; one raw s_barrier per K-step, counted s_waitcnt vmcnt(N) (never 0 in steady state).
+//   * zero padding / tile tails: the lane's buffer offset is pushed out of range, the hardware writes zeros;
+//   * LDS rows are 64 B unpadded (DMA writes lane-linear), bank conflicts are removed by XOR-swizzling the
+//     16-B chunk index with (row >> 2) & 3 on the SOURCE side and again on the ds_read_b128 side.
+// =====================================================================================================
+typedef __attribute__((address_space(3))) void* lds_void_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n) {   // n is wave-uniform
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<1>(); break;
+    case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
+    case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;
+    case 7: wait_vmcnt<7>(); break;
+    default: wait_vmcnt<8>(); break;
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256)
+conv_gemm_dma_kernel(const mireg_conv_desc p) {
+  constexpr int CPC = Cfg<T>::CPC, BK = Cfg<T>::BK;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int STAGES = 4;
+  constexpr int A_GROUPS = BM / 16, B_GROUPS = BN / 16;          // 16-row groups = one DMA wave-instruction each
+  constexpr int A_PW = A_GROUPS / 4;                               // per wave
+  constexpr int B_PW = (B_GROUPS + 3) / 4;
+  constexpr int STAGE_BYTES = (BM + BN) * 64;
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_GROUPS % 4 == 0, "bad tile");
+  constexpr int EPI_BYTES = BM * BN * 4 + BM * 8;
+  constexpr int SMEM_BYTES = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so give each XCD a contiguous
+  // run of tiles (neighbouring m-tiles x all n-tiles): its 4 MiB L2 then holds that run's pixels and the weights.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int gHW = p.g_H * p.g_W;
+  const int M = p.n_img * gHW;
+  const int K = p.taps_y * p.taps_x * p.x_C;
+  const int nk_total = (K + BK - 1) / BK;
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.split_k > 1) {
+    const int per = (nk_total + p.split_k - 1) / p.split_k;
+    kt_begin = blockIdx.z * per;
+    kt_end = min(nk_total, kt_begin + per);
+  }
+
+  // ---- DMA source state: lane L of a group covers row L>>2, physical chunk L&3 = logical chunk ^ swizzle ----
+  constexpr unsigned kOOB = 0x80000000u;
+  const int lrow = lane >> 2;
+  const int kc = (lane & 3) ^ ((lane >> 4) & 3);                   // logical 16-B chunk of the K-step this lane fetches
+  unsigned a_base[A_PW];                                            // byte offset of the image, or OOB
+  int a_iy0[A_PW], a_ix0[A_PW];
+#pragma unroll
+  for (int c = 0; c < A_PW; ++c) {
+    const int m = m0 + (wid + 4 * c) * 16 + lrow;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int img = mm / gHW, rem = mm - img * gHW;
+    const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
+    a_base[c] = ok ? (unsigned)((long)img * p.x_H * p.x_W * p.x_ld * (long)sizeof(T)) : kOOB;
+    a_iy0[c] = gy * p.mul_y + p.off_y;
+    a_ix0[c] = gx * p.mul_x + p.off_x;
+  }
+  unsigned b_base[B_PW];
+#pragma unroll
+  for (int c = 0; c < B_PW; ++c) {
+    const int g = wid + 4 * c;
+    const int n = n0 + g * 16 + lrow;
+    b_base[c] = (g < B_GROUPS && n < p.N) ? (unsigned)((long)n * p.w_ld * (long)sizeof(T)) : kOOB;
+  }
+  const int cpt = p.x_C / CPC;
+  int ty, tx, cc;
+  {
+    const int q = kt_begin * 4 + kc;
+    const int tap = q / cpt;
+    cc = q - tap * cpt;
+    ty = tap / p.taps_x;
+    tx = tap - ty * p.taps_x;
+  }
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  // running source offsets: a_cur = byte offset of (row, current tap, channel 0) or OOB; recomputed only when the
+  // lane's chunk walks into the next tap, so the steady-state K-step costs a handful of VALU ops per DMA
+  unsigned a_cur[A_PW];
+  auto set_tap = [&]() {
+    const bool kvalid = ty < p.taps_y;
+#pragma unroll
+    for (int c = 0; c < A_PW; ++c) {
+      const int iy = a_iy0[c] + ty * p.step_y, ix = a_ix0[c] + tx * p.step_x;
+      const bool ok = kvalid && a_base[c] != kOOB && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
+      a_cur[c] = ok ? a_base[c] + (unsigned)((((long)iy * p.x_W + ix) * p.x_ld) * (long)sizeof(T)) : kOOB;
+    }
+  };
+  set_tap();
+  unsigned b_k = (unsigned)((kt_begin * BK + kc * CPC) * (int)sizeof(T));      // byte offset along K of this lane's chunk
+  const unsigned b_kend = (unsigned)(K * (int)sizeof(T));
+
+  auto issue = [&](int stage) {
+    unsigned char* As = smem + stage * STAGE_BYTES;
+    unsigned char* Bs = As + BM * 64;
+    const unsigned ccb = (unsigned)(cc * 16);
+#pragma unroll
+    for (int c = 0; c < A_PW; ++c) {
+      const unsigned off = a_cur[c] != kOOB ? a_cur[c] + ccb : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t)(As + (wid + 4 * c) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < B_PW; ++c) {
+      if (wid + 4 * c < B_GROUPS) {                                 // wave-uniform
+        const unsigned off = (b_base[c] != kOOB && b_k < b_kend) ? b_base[c] + b_k : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_t)(Bs + (wid + 4 * c) * 1024), 16, off, 0, 0, 0);
+      }
+    }
+    b_k += BK * (int)sizeof(T);
+    cc += 4;
+    if (cc >= cpt) {
+      do { cc -= cpt; if (++tx == p.taps_x) { tx = 0; ++ty; } } while (cc >= cpt);
+      set_tap();
+    }
+  };
+  int loads_per_tile = A_PW;                                         // DMA instructions this wave issues per K-step
+#pragma unroll
+  for (int c = 0; c < B_PW; ++c) loads_per_tile += (wid + 4 * c < B_GROUPS) ? 1 : 0;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = kt_end - kt_begin;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s);
+
+  // fragment read offsets (bytes inside a stage): row*64 + ((chunk ^ swz(row)) * 16), swz(row) = (row>>2)&3
+  int a_off[TM], b_off[TN], a_swz[TM], b_swz[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { const int row = wm * WTM + i * 32 + r; a_off[i] = row * 64; a_swz[i] = (row >> 2) & 3; }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { const int row = wn * WTN + j * 32 + r; b_off[j] = BM * 64 + row * 64; b_swz[j] = (row >> 2) & 3; }
+
+  auto compute = [&](int stage) {
+    const unsigned char* st = smem + stage * STAGE_BYTES;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + (((ks * 2 + h) ^ a_swz[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + (((ks * 2 + h) ^ b_swz[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        f32x4 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + a_off[i] + (((g * 2 + h) ^ a_swz[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const f32x4*>(st + b_off[j] + (((g * 2 + h) ^ b_swz[j]) << 4));
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bfr[j][t], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // steady state: tile `it` has landed once at most 2 younger tiles (2 * loads_per_tile DMAs) are outstanding
+  int it = 0;
+  const int steady = nk - (STAGES - 1);
+  if (loads_per_tile == A_PW + B_PW) {                               // every wave of 128/64-wide tiles: immediate count
+    const bool no_issue = p.accumulate & 4, no_compute = p.accumulate & 2;   // ABLATION ONLY
+    for (; it < steady; ++it) {
+      wait_vmcnt<2 * (A_PW + B_PW)>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (!no_issue) issue((it + STAGES - 1) % STAGES);
+      if (!no_compute) compute(it % STAGES);
+    }
+  } else {
+    for (; it < steady; ++it) {
+      wait_vmcnt_dyn(2 * loads_per_tile);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue((it + STAGES - 1) % STAGES);
+      compute(it % STAGES);
+    }
+  }
+  for (; it < nk; ++it) {                                            // drain: nothing left to issue
+    wait_vmcnt_dyn(min(STAGES - 2, nk - 1 - it) * loads_per_tile);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(it % STAGES);
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32 [BM][BN], reusing the ring) -> 16-byte coalesced row stores ------
+  __syncthreads();                                                   // every wave is done with the ring
+  float* ct = reinterpret_cast<float*>(smem);
+  long* rowoff = reinterpret_cast<long*>(smem + BM * BN * 4);        // BM entries (ring is >= BM*BN*4 + BM*8 bytes)
+  const bool slab_out = p.split_k > 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = wn * WTN + j * 32 + r, n = n0 + nl;
+      const float bv = (!slab_out && p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ml = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float v = acc[i][j][e];
+        if (!slab_out) { v += bv; v = v > 0.f ? v : v * p.slope; }
+        ct[ml * BN + nl] = v;
+      }
+    }
+  if (tid < BM) {
+    const int m = m0 + tid;
+    long off = -1;
+    if (m < M) {
+      if (slab_out) off = ((long)blockIdx.z * M + m) * p.N;
+      else {
+        const int img = m / gHW, rem = m - img * gHW;
+        const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
+        off = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
+      }
+    }
+    rowoff[tid] = off;
+  }
+  __syncthreads();
+  if (slab_out) {
+    constexpr int CPR = BN / 4;                                      // float4 chunks per row
+    const bool vec = (p.N % 4) == 0;
+    for (int c = tid; c < BM * CPR; c += 256) {
+      const int ml = c / CPR, nl = (c - ml * CPR) * 4, n = n0 + nl;
+      const long off = rowoff[ml];
+      if (off < 0 || n >= p.N) continue;
+      const float4 v = *reinterpret_cast<const float4*>(ct + ml * BN + nl);
+      float* d = p.slab + off + n;
+      if (vec) stg_u4(d, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+      else { const float vv[4] = {v.x, v.y, v.z, v.w}; for (int q = 0; q < 4 && n + q < p.N; ++q) d[q] = vv[q]; }
+    }
+    return;
+  }
+  T* __restrict__ yp = reinterpret_cast<T*>(p.y);
+  constexpr int V = 16 / (int)sizeof(T);                              // output elements per 16-byte store
+  constexpr int CPR = BN / V;
+  const bool vec = yp && (p.y_ld % V) == 0 && (reinterpret_cast<uintptr_t>(yp) % 16) == 0;
+  for (int c = tid; c < BM * CPR; c += 256) {
+    const int ml = c / CPR, nl = (c - ml * CPR) * V, n = n0 + nl;
+    const long pix = rowoff[ml];
+    if (pix < 0 || n >= p.N) continue;
+    float v[V];
+#pragma unroll
+    for (int q = 0; q < V; q += 4) {
+      const float4 t4 = *reinterpret_cast<const float4*>(ct + ml * BN + nl + q);
+      v[q] = t4.x; v[q + 1] = t4.y; v[q + 2] = t4.z; v[q + 3] = t4.w;
+    }
+    if (yp) {
+      T* d = yp + pix * p.y_ld + n;
+      if (vec && n + V <= p.N) {
+        Chunk o;
+        if (p.accumulate & 1) {
+          const Chunk old = ldg_chunk(d);
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[2 * q] += __uint_as_float(old.w[q] << 16); v[2 * q + 1] += __uint_as_float(old.w[q] & 0xffff0000u); }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += __uint_as_float(old.w[q]);
+          }
+        }
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+            const bf2 t2 = {(__bf16)v[2 * q], (__bf16)v[2 * q + 1]};
+            o.w[q] = __builtin_bit_cast(uint32_t, t2);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o.w[q] = __float_as_uint(v[q]);
+        }
+        stg_u4(d, make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]));
+      } else {
+        for (int q = 0; q < V && n + q < p.N; ++q) {
+          float vv = v[q];
+          if (p.accumulate & 1) vv += to_f32(d[q]);
+          d[q] = from_f32<T>(vv);
+          v[q] = vv;
+        }
+      }
+    }
+    if (p.y32) for (int q = 0; q < V && n + q < p.N; ++q) p.y32[pix * p.y32_ld + n + q] = v[q];
+  }
+}
+
 // split-K second pass: y = act(sum_z slab[z] + bias) with the same pixel mapping as the main epilogue
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -251,7 +587,7 @@ splitk_reduce_kernel(const mireg_conv_desc p) {
     const long pix = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
     if (yp) {
       T* d = yp + pix * p.y_ld + n;
-      if (p.accumulate) v += to_f32(*d);
+      if (p.accumulate & 1) v += to_f32(*d);
       *d = from_f32<T>(v);
     }
     if (p.y32) p.y32[pix * p.y32_ld + n] = v;
@@ -432,19 +768,28 @@ conv_wgrad_kernel(const mireg_conv_desc p) {
     }
 }
 
+bool use_v1() {
+  static const int v = [] { const char* e = getenv("MIREG_GEMM_V1"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+
 template <typename T>
 int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
   const long M = (long)p.n_img * p.g_H * p.g_W;
   const int z = p.split_k > 1 ? p.split_k : 1;
+  const bool dma = !use_v1() && p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < (1L << 31) && p.w_bytes < (1L << 31);
   if (p.N > 64) {
     dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 127) / 128)), 1, z);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, stream, p);
+    if (dma) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, stream, p);
   } else if (p.N > 32) {
     dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 63) / 64)), 1, z);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, stream, p);
+    if (dma) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, stream, p);
   } else {
     dim3 grid((unsigned)((M + 127) / 128), 1, z);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1>), grid, dim3(256), 0, stream, p);
+    if (dma) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 32, 4, 1>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1>), grid, dim3(256), 0, stream, p);
   }
   if (z > 1) {
     const long total = M * p.N;

@@ -1,0 +1,219 @@
+// correlation.hip -- cost volume (K7/K8) and PWC feature warp (K10) for gfx950, NHWC views.
+//
+// Correlation(pad=md, kernel=1, max_displacement=md, stride1=1, stride2=s2) as the reference uses it at
+// flownet2/networks/FlowNetC.py:31,88 (md=20, s2=2 -> 441 ch) and PWC/models/PWCNet.py:69,200-259 (md=4, s2=1 -> 81 ch):
+//   out[b,y,x,(dy+R)*D+(dx+R)] = act( (1/C) * sum_c f1[b,y,x,c] * f2[b,y+s2*dy,x+s2*dx,c] ),  zero outside f2
+// The third-party CUDA kernel (one 32-thread block per output pixel, serial over displacements) is latency bound
+// and re-reads f2 D^2 times.  Here every (b, y, dy) is a 32 x 32 x C product  f1row . f2row^T  on the matrix
+// cores (one wave each, operands straight from L1/L2 as 16-byte fragments): the band |x'-x| <= md with matching
+// stride2 parity is then picked out of the 32x32 tile through LDS and written as coalesced channel runs.  That
+// turns 441 (81) scalar dot products per pixel into 21 (9) MFMA tiles and leaves the kernel bound by the output
+// write (HBM), which a VALU + shuffle formulation cannot reach at fp32 rate.
+#include "mireg_common.h"
+#include "../../include/mireg.h"
+
+using namespace mireg;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GPTR(T, p) (reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p)))
+#else
+#define GPTR(T, p) (reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p)))
+#endif
+
+__device__ __forceinline__ float ldf(const float* p) { return *GPTR(const float, p); }
+__device__ __forceinline__ float ldf(const __bf16* p) { return (float)*GPTR(const __bf16, p); }
+__device__ __forceinline__ void stf(float* p, float v) { *GPTR(float, p) = v; }
+__device__ __forceinline__ void stf(__bf16* p, float v) { *GPTR(__bf16, p) = (__bf16)v; }
+
+// one wave = one (b, y, 32-pixel x tile); loops over dy and the x' tiles the band touches
+template <typename T>
+__global__ void __launch_bounds__(256)
+correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__ f2, long ld2, T* __restrict__ out, long ldo,
+                       int B, int H, int W, int C, int c_norm, int R, int s2, float slope) {
+  __shared__ float tile_s[4][32][33];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int D = 2 * R + 1;
+  const int xt = (W + 31) / 32;
+  const long units = (long)B * H * xt;
+  const float inv_c = 1.f / (float)c_norm;
+  float (*tile)[33] = tile_s[wid];
+  for (long u = (long)blockIdx.x * 4 + wid; u < units; u += (long)gridDim.x * 4) {
+    const int x0 = (int)(u % xt) * 32;
+    const int y = (int)((u / xt) % H);
+    const int b = (int)(u / ((long)xt * H));
+    const int xa = x0 + r;                                   // this lane's f1 pixel (A row)
+    const T* a_row = f1 + (((long)b * H + y) * W + min(xa, W - 1)) * ld1;
+    const bool a_ok = xa < W;
+    for (int dyi = 0; dyi < D; ++dyi) {
+      const int yy = y + (dyi - R) * s2;
+      T* o_row = out + (((long)b * H + y) * W) * ldo + dyi * D;
+      if (yy < 0 || yy >= H) {                               // whole displacement row outside f2: zeros
+        for (int e = lane; e < 32 * D; e += 64) {
+          const int px = e / D, dxi = e - px * D;
+          if (x0 + px < W) stf(o_row + (long)(x0 + px) * ldo + dxi, 0.f);
+        }
+        continue;
+      }
+      // x' tiles that intersect [x0 - R*s2, x0 + 31 + R*s2]
+      const int t_lo = max(0, (x0 - R * s2) >> 5), t_hi = min(xt - 1, (x0 + 31 + R * s2) >> 5);
+      // first pass zeroes the band (covers displacements that fall outside [0, W)), later passes fill hits
+      for (int e = lane; e < 32 * D; e += 64) {
+        const int px = e / D, dxi = e - px * D;
+        const int xx = x0 + px + (dxi - R) * s2;
+        if (x0 + px < W && (xx < 0 || xx >= W)) stf(o_row + (long)(x0 + px) * ldo + dxi, 0.f);
+      }
+      for (int t = t_lo; t <= t_hi; ++t) {
+        const int xb = t * 32 + r;                             // this lane's f2 pixel (B column)
+        const T* b_row = f2 + (((long)b * H + yy) * W + min(xb, W - 1)) * ld2;
+        const bool b_ok = xb < W;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        if constexpr (sizeof(T) == 2) {
+          for (int k = 0; k < C; k += 16) {                    // C % 8 == 0; a trailing half step is zero-filled
+            const int kk = k + 8 * h;
+            uint4 av = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
+            if (a_ok && kk < C) av = *GPTR(const uint4, a_row + kk);
+            if (b_ok && kk < C) bv = *GPTR(const uint4, b_row + kk);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+          }
+        } else {
+          for (int k = 0; k < C; k += 8) {                     // lane (r,h) feeds K slots k+4h..k+4h+3, one per MFMA
+            const int kk = k + 4 * h;
+            float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+            if (a_ok && kk < C) av = *GPTR(const float4, a_row + kk);
+            if (b_ok && kk < C) bv = *GPTR(const float4, b_row + kk);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+          }
+        }
+        // acc[e] = <f1[x0 + row], f2[32 t + col]>, col = lane&31, row = (e&3) + 8*(e>>2) + 4*h
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[(e & 3) + 8 * (e >> 2) + 4 * h][r] = acc[e];
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < 32 * D; e += 64) {
+          const int px = e / D, dxi = e - px * D;
+          const int xx = x0 + px + (dxi - R) * s2;             // f2 pixel of this displacement
+          if (x0 + px < W && xx >= t * 32 && xx < t * 32 + 32 && xx < W) {
+            float v = tile[px][xx - t * 32] * inv_c;
+            v = v > 0.f ? v : v * slope;
+            stf(o_row + (long)(x0 + px) * ldo + dxi, v);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
+// PWCDCNet.warp (PWC/models/PWCNet.py:143-179): grid normalised with (W-1) but sampled with align_corners=False,
+// so the tap coordinate is ((2(x+u)/(W-1) - 1 + 1) * W - 1) / 2; output * (bilinear(ones) >= 0.9999).
+template <typename T>
+__global__ void __launch_bounds__(256)
+pwc_warp_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ flow, long ldf_, float flow_scale,
+                    T* __restrict__ out, long ldo, int B, int H, int W, int C) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int cpr = C / V;
+  const long total = (long)B * H * W * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)
+    const long pix = i / cpr;
+    const int c0 = (int)(i - pix * cpr) * V;
+    const int xq = (int)(pix % W), yq = (int)((pix / W) % H);
+    const long img = pix / ((long)W * H);
+    const float u = flow[pix * ldf_] * flow_scale, v = flow[pix * ldf_ + 1] * flow_scale;
+    const float gx = 2.0f * ((float)xq + u) / (float)max(W - 1, 1) - 1.0f;
+    const float gy = 2.0f * ((float)yq + v) / (float)max(H - 1, 1) - 1.0f;
+    const float px = ((gx + 1.f) * (float)W - 1.f) / 2.f, py = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    const float fx = floorf(px), fy = floorf(py);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = px - fx, wy1 = py - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    float acc[V], msk = 0.f;
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+      const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
+      if (xi < 0 || xi >= W || yi < 0 || yi >= H) continue;
+      msk += wgt;
+      const T* src = x + ((img * H + yi) * W + xi) * ldx + c0;
+#pragma unroll
+      for (int q = 0; q < V; ++q) acc[q] += ldf(src + q) * wgt;
+    }
+    const float m = msk < 0.9999f ? 0.f : 1.f;
+    T* dst = out + pix * ldo + c0;
+#pragma unroll
+    for (int q = 0; q < V; ++q) stf(dst + q, acc[q] * m);
+  }
+}
+
+// dst[m][0..C) = src[m][0..C)  (concat staging where a producer cannot write in place; any channel offset)
+template <typename T>
+__global__ void __launch_bounds__(256)
+copy_channels_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd, long M, int C) {
+  const long total = M * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / C; const int c = (int)(i - m * C);
+    *GPTR(T, dst + m * ldd + c) = *GPTR(const T, src + m * lds_ + c);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mireg_copy_channels(const void* src, long ld_s, void* dst, long ld_d, long M, int C, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(src && dst && M > 0 && C > 0);
+  long g = (M * C + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((copy_channels_kernel<__bf16>), dim3((unsigned)g), dim3(256), 0, stream, (const __bf16*)src, ld_s, (__bf16*)dst, ld_d, M, C);
+  else hipLaunchKernelGGL((copy_channels_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, ld_s, (float*)dst, ld_d, M, C);
+  MIREG_LAUNCH_RET();
+}
+
+
+int mireg_correlation_fwd(const void* f1, long ld1, const void* f2, long ld2, void* out, long ldo, int B, int H, int W,
+                          int C, int c_norm, int max_displacement, int stride2, float slope, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(f1 && f2 && out && B > 0 && H > 0 && W > 0 && C > 0 && c_norm > 0 && stride2 > 0 && max_displacement >= 0);
+  MIREG_CHECK_ARG(max_displacement % stride2 == 0 && max_displacement / stride2 <= 15);
+  const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
+  MIREG_CHECK_ARG(C % V == 0 && ld1 % V == 0 && ld2 % V == 0 && (uintptr_t)f1 % 16 == 0 && (uintptr_t)f2 % 16 == 0);
+  const long units = (long)B * H * ((W + 31) / 32);
+  long g = (units + 3) / 4;
+  if (g > 4096) g = 4096;
+  const int R = max_displacement / stride2;
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((correlation_fwd_kernel<__bf16>), dim3((unsigned)g), dim3(256), 0, stream, (const __bf16*)f1, ld1, (const __bf16*)f2, ld2, (__bf16*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
+  else if (dtype == MIREG_DTYPE_F32)
+    hipLaunchKernelGGL((correlation_fwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)f1, ld1, (const float*)f2, ld2, (float*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
+  else return MIREG_ERR_ARG;
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_pwc_warp_fwd(const void* x, long ldx, const float* flow, long ldf_, float flow_scale, void* out, long ldo, int B,
+                       int H, int W, int C, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(x && flow && out && B > 0 && H > 0 && W > 0 && C > 0 && ldf_ >= 2);
+  const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
+  MIREG_CHECK_ARG(C % V == 0);
+  const long total = (long)B * H * W * (C / V);
+  long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((pwc_warp_fwd_kernel<__bf16>), dim3((unsigned)g), dim3(256), 0, stream, (const __bf16*)x, ldx, flow, ldf_, flow_scale, (__bf16*)out, ldo, B, H, W, C);
+  else if (dtype == MIREG_DTYPE_F32)
+    hipLaunchKernelGGL((pwc_warp_fwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)x, ldx, flow, ldf_, flow_scale, (float*)out, ldo, B, H, W, C);
+  else return MIREG_ERR_ARG;
+  MIREG_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -39,7 +39,7 @@ class ConvDesc(ctypes.Structure):
                 ("y_mul_y", ctypes.c_int), ("y_mul_x", ctypes.c_int), ("y_off_y", ctypes.c_int), ("y_off_x", ctypes.c_int),
                 ("y32", ctypes.c_void_p), ("y32_ld", ctypes.c_long),
                 ("bias", ctypes.c_void_p), ("slope", ctypes.c_float), ("accumulate", ctypes.c_int), ("dtype", ctypes.c_int),
-                ("split_k", ctypes.c_int), ("slab", ctypes.c_void_p)]
+                ("split_k", ctypes.c_int), ("slab", ctypes.c_void_p), ("x_bytes", ctypes.c_long), ("w_bytes", ctypes.c_long)]
 
 
 class PackClass(ctypes.Structure):
@@ -117,6 +117,11 @@ class View:
     @property
     def rows(self) -> int:
         return self.B * self.H * self.W
+
+    @property
+    def bytes_left(self) -> int:
+        """Readable bytes from this view's first element to the end of its buffer."""
+        return (self.buf.numel() - self.c0) * self.buf.element_size()
 
     def slice(self, c0: int, C: int) -> "View":
         assert c0 >= 0 and self.c0 + c0 + C <= self.ld
@@ -274,6 +279,7 @@ class ConvLayer:
         d.step_y = d.step_x = self.d
         d.g_H, d.g_W, d.n_img = Ho, Wo, x.B
         d.w, d.w_ld, d.N = self.packF.data_ptr(), self.Kf, self.Co
+        d.x_bytes, d.w_bytes = x.bytes_left, self.packF.numel() * self.packF.element_size()
         self._fill_out(d, y, y32, Ho, Wo, 1, 1, 0, 0)
         d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
         d.slope, d.accumulate = slope, int(accumulate)
@@ -318,6 +324,7 @@ class ConvLayer:
                 d.step_y = d.step_x = -1
             d.g_H, d.g_W, d.n_img = gH, gW, g.B
             d.w, d.w_ld, d.N = c["pack"].data_ptr(), c["pack"].shape[1], self.Ci
+            d.x_bytes, d.w_bytes = g.bytes_left, c["pack"].numel() * c["pack"].element_size()
             self._fill_out(d, out, y32, o.H, o.W, self.s, self.s, c["py"], c["px"])
             d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
             d.slope, d.accumulate = slope, int(accumulate)

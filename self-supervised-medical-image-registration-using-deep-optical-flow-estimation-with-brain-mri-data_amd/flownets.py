@@ -101,7 +101,35 @@ class PredictorEngineBase:
         return out
 
 
-class FlowNetSEngine(PredictorEngineBase):
+class FlowNetDecoderMixin:
+    """Refinement decoder shared by FlowNetS and FlowNetC (FlowNetS.py:60-80, flownet2/networks/FlowNetC.py:104-125):
+    needs self.cat{2..5}, self.a61, self.skip_c, self.hs and the module's deconv / predict_flow / upsampler layers."""
+
+    def setup_decoder(self, m: nn.Module) -> None:
+        for lvl in DECONV:
+            self.add_conv(f"deconv{lvl}", getattr(m, f"deconv{lvl}")[0], 2, 1)        # adjoint conv: Co=cin_deconv
+        for lvl in PREDICT:
+            self.add_conv(f"predict_flow{lvl}", getattr(m, f"predict_flow{lvl}"), 1, 1)
+        for lvl in (6, 5, 4, 3):
+            self.add_conv(f"up{lvl}", getattr(m, f"upsampled_flow{lvl}_to_{lvl - 1}"), 2, 1)
+        new, B, hs = self.ws.new, self.B, self.hs
+        self.flow32 = {lvl: new(B, *hs[lvl], 2, dtype=F32, pad=2) for lvl in PREDICT}
+        self.flowT = {lvl: new(B, *hs[lvl], 2) for lvl in PREDICT}
+
+    def decoder_forward(self) -> None:
+        L, c = self.layers, self.cat
+        feat = self.a61
+        L["predict_flow6"].run_fwd_form(feat, self.flowT[6], y32=self.flow32[6])
+        for lvl in (5, 4, 3, 2):
+            cs = self.skip_c[lvl]
+            cd = DECONV[lvl][1]
+            L[f"up{lvl + 1}"].run_dgrad_form(self.flowT[lvl + 1], c[lvl].slice(cs + cd, 2), bias=True)
+            L[f"deconv{lvl}"].run_dgrad_form(feat, c[lvl].slice(cs, cd), slope=SLOPE, bias=True)
+            feat = c[lvl]
+            L[f"predict_flow{lvl}"].run_fwd_form(feat, self.flowT[lvl], y32=self.flow32[lvl])
+
+
+class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
     def __init__(self, module: "FlowNetS", B: int, H: int, W: int, device, dtype: torch.dtype):
         super().__init__(module, B, H, W, device, dtype)
         if H % 64 or W % 64:
@@ -113,15 +141,10 @@ class FlowNetSEngine(PredictorEngineBase):
             self.add_conv(name, seq[0], s, (k - 1) // 2)
             if self.bn:
                 self.bns[name] = BatchNormAct(seq[1], ws, SLOPE)
-        for lvl in DECONV:
-            self.add_conv(f"deconv{lvl}", getattr(m, f"deconv{lvl}")[0], 2, 1)        # adjoint conv: Co=cin_deconv
-        for lvl in PREDICT:
-            self.add_conv(f"predict_flow{lvl}", getattr(m, f"predict_flow{lvl}"), 1, 1)
-        for lvl in (6, 5, 4, 3):
-            self.add_conv(f"up{lvl}", getattr(m, f"upsampled_flow{lvl}_to_{lvl - 1}"), 2, 1)
         # ---- buffers -----------------------------------------------------------------------------
         hs = {lvl: (H >> lvl, W >> lvl) for lvl in range(1, 7)}
         self.hs = hs
+        self.setup_decoder(m)
         new = ws.new
         self.x8 = new(B, H, W, 2)
         self.a1 = new(B, *hs[1], 64)
@@ -132,8 +155,6 @@ class FlowNetSEngine(PredictorEngineBase):
         enc_out = {"conv1": (1, 64), "conv2": (2, 128), "conv3": (3, 256), "conv3_1": (3, 256), "conv4": (4, 512),
                    "conv4_1": (4, 512), "conv5": (5, 512), "conv5_1": (5, 512), "conv6": (6, 1024), "conv6_1": (6, 1024)}
         self.raw = {n: new(B, *hs[l], c) for n, (l, c) in enc_out.items()} if self.bn else {}
-        self.flow32 = {lvl: new(B, *hs[lvl], 2, dtype=F32, pad=2) for lvl in PREDICT}
-        self.flowT = {lvl: new(B, *hs[lvl], 2) for lvl in PREDICT}
         self.flow0 = new(B, 256, 256, 2, dtype=F32, pad=2)
         # where each encoder conv reads / writes
         c = self.cat
@@ -158,15 +179,7 @@ class FlowNetSEngine(PredictorEngineBase):
                 self.bns[name].forward(self.raw[name], dst, training)
             else:
                 L[name].run_fwd_form(src, dst, slope=SLOPE)
-        feat = self.a61
-        L["predict_flow6"].run_fwd_form(feat, self.flowT[6], y32=self.flow32[6])
-        for lvl in (5, 4, 3, 2):
-            cs = self.skip_c[lvl]
-            cd = DECONV[lvl][1]
-            L[f"up{lvl + 1}"].run_dgrad_form(self.flowT[lvl + 1], c[lvl].slice(cs + cd, 2), bias=True)
-            L[f"deconv{lvl}"].run_dgrad_form(feat, c[lvl].slice(cs, cd), slope=SLOPE, bias=True)
-            feat = c[lvl]
-            L[f"predict_flow{lvl}"].run_fwd_form(feat, self.flowT[lvl], y32=self.flow32[lvl])
+        self.decoder_forward()
         f2 = self.flow32[2]
         _lib.call("mireg_resize_bilinear_fwd", f2.ptr, self.flow0.ptr, self.B, 2, f2.H, f2.W, 256, 256,
                   f2.H * f2.W * 2, 1, 2, 256 * 256 * 2, 1, 2, 0, _stream())

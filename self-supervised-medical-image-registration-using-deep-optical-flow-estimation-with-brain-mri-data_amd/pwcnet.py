@@ -1,0 +1,187 @@
+"""PWC-DC-Net (reference PWC/models/PWCNet.py:38-279, 1-channel pyramid) on the HIP engine.
+
+Same submodule names / state_dict keys as the reference; returns the 7 flows (256^2 .. 4^2 for a 256^2
+input) in both train and eval mode.  Every torch.cat of the DenseNet-style estimators is
+replaced by channel-offset writes: each level owns ONE buffer laid out
+    [conv_4 32 | conv_3 64 | conv_2 96 | conv_1 128 | conv_0 128 | corr 81 | c1 C_l | up_flow 2 | up_feat 2]
+so that conv_j reads the suffix that starts at its own output's end (all suffix offsets are multiples of 32).
+Forward is implemented; the backward (correlation / warp backward kernels) is scheduled next.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .correlation import Correlation, correlation_views, pwc_warp_views
+from .engine import F32, View, _stream, cast_from_f32, nchw_to_view
+from .flownets import PredictorEngineBase
+
+SLOPE = 0.1
+PYRAMID = [(1, 16), (16, 32), (32, 64), (64, 96), (96, 128), (128, 196)]      # PWCNet.py:50-67
+PYR_NAMES = {1: ("conv1a", "conv1aa", "conv1b"), 2: ("conv2a", "conv2aa", "conv2b"), 3: ("conv3a", "conv3aa", "conv3b"),
+             4: ("conv4a", "conv4aa", "conv4b"), 5: ("conv5a", "conv5aa", "conv5b"), 6: ("conv6aa", "conv6a", "conv6b")}
+DENSE = [128, 128, 96, 64, 32]                                                  # PWCNet.py:73-80
+DENSE_OFF = [320, 192, 96, 32, 0]                                               # where conv_j writes; it reads [off+cout:]
+BASE = 448                                                                       # start of [corr | c1 | up_flow | up_feat]
+FLOW_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}                                 # PWCNet.py:214-258
+FEAT_C = {6: 196, 5: 128, 4: 96, 3: 64, 2: 32}
+DC = [(128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1)]                  # PWCNet.py:128-133
+
+
+def _conv(cin, cout, k=3, stride=1, padding=1, dilation=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, padding, dilation, bias=True), nn.LeakyReLU(SLOPE))
+
+
+class PWCEngine(PredictorEngineBase):
+    def __init__(self, module: "PWCDCNet", B: int, H: int, W: int, device, dtype: torch.dtype):
+        super().__init__(module, B, H, W, device, dtype)
+        if H % 64 or W % 64:
+            raise RuntimeError(f"PWC engine needs H, W divisible by 64, got {H}x{W}")
+        m, ws, new = module, self.ws, self.ws.new
+        self.md = m.md
+        self.nd = (2 * m.md + 1) ** 2
+        hs = {lvl: (H >> lvl, W >> lvl) for lvl in range(0, 7)}
+        self.hs = hs
+        for lvl in range(1, 7):
+            for i, n in enumerate(PYR_NAMES[lvl]):
+                self.add_conv(n, getattr(m, n)[0], 2 if i == 0 else 1, 1)
+        for lvl in (6, 5, 4, 3, 2):
+            for j in range(5):
+                self.add_conv(f"conv{lvl}_{j}", getattr(m, f"conv{lvl}_{j}")[0], 1, 1)
+            self.add_conv(f"predict_flow{lvl}", getattr(m, f"predict_flow{lvl}"), 1, 1)
+            if lvl > 2:
+                self.add_conv(f"deconv{lvl}", getattr(m, f"deconv{lvl}"), 2, 1)
+                self.add_conv(f"upfeat{lvl}", getattr(m, f"upfeat{lvl}"), 2, 1)
+        self.add_conv("deconv2", m.deconv2, 2, 1)
+        self.add_conv("deconv1", m.deconv1, 2, 1)
+        for i, (_, d) in enumerate(DC, start=1):
+            self.add_conv(f"dc_conv{i}", getattr(m, f"dc_conv{i}")[0], 1, d, d)
+        self.add_conv("dc_conv7", m.dc_conv7, 1, 1)
+        # ---- buffers ---------------------------------------------------------------------------------
+        self.img = {s: new(B, H, W, 1) for s in "ab"}
+        self.pyr = {(lvl, s, i): new(B, *hs[lvl], PYRAMID[lvl - 1][1]) for lvl in range(1, 7) for s in "ab" for i in range(3)}
+        self.x = {lvl: new(B, *hs[lvl], BASE + self.nd + (0 if lvl == 6 else FEAT_C[lvl] + 4)) for lvl in (6, 5, 4, 3, 2)}
+        self.warped = {lvl: new(B, *hs[lvl], FEAT_C[lvl]) for lvl in (5, 4, 3, 2)}
+        self.flow32 = {lvl: new(B, *hs[lvl], 2, dtype=F32, pad=2) for lvl in range(0, 7)}
+        self.flowT = {lvl: new(B, *hs[lvl], 2) for lvl in range(1, 7)}
+        self.upflow32 = {lvl: new(B, *hs[lvl], 2, dtype=F32, pad=2) for lvl in (5, 4, 3, 2)}
+        self.dc = [new(B, *hs[2], c) for c, _ in DC]
+        self.dc7 = new(B, *hs[2], 2)
+
+    def forward(self, x: torch.Tensor, training: bool) -> List[torch.Tensor]:
+        L, code, st = self.layers, self.ws.code, _stream()
+        self.training_cache = training
+        self.pack_weights()
+        x = x.contiguous()
+        nchw_to_view(x, 0, 1, self.img["a"])
+        nchw_to_view(x, 1, 1, self.img["b"])
+        for s in "ab":                                         # siamese feature pyramid (PWCNet.py:186-197)
+            src = self.img[s]
+            for lvl in range(1, 7):
+                for i, n in enumerate(PYR_NAMES[lvl]):
+                    dst = self.pyr[(lvl, s, i)]
+                    L[n].run_fwd_form(src, dst, slope=SLOPE)
+                    src = dst
+        feat = lambda lvl, s: self.pyr[(lvl, s, 2)]
+        for lvl in (6, 5, 4, 3, 2):
+            X = self.x[lvl]
+            c1, c2 = feat(lvl, "a"), feat(lvl, "b")
+            od = self.nd + (0 if lvl == 6 else FEAT_C[lvl] + 4)
+            if lvl == 6:
+                correlation_views(c1, c2, X.slice(BASE, self.nd), FEAT_C[6], self.md, 1, SLOPE, code)
+            else:
+                # up_flow / up_feat were written into X by the previous level; warp c2 with the scaled up_flow
+                pwc_warp_views(c2, self.upflow32[lvl], FLOW_SCALE[lvl], self.warped[lvl], code)
+                correlation_views(c1, self.warped[lvl], X.slice(BASE, self.nd), FEAT_C[lvl], self.md, 1, SLOPE, code)
+                _lib.call("mireg_copy_channels", c1.ptr, c1.ld, X.slice(BASE + self.nd, FEAT_C[lvl]).ptr, X.ld, c1.rows,
+                          FEAT_C[lvl], code, st)
+            for j in range(5):                                 # DenseNet estimator: conv_j reads the suffix, writes in front
+                off, cout = DENSE_OFF[j], DENSE[j]
+                L[f"conv{lvl}_{j}"].run_fwd_form(X.slice(off + cout, X.C - off - cout), X.slice(off, cout), slope=SLOPE)
+            L[f"predict_flow{lvl}"].run_fwd_form(X, self.flowT[lvl], y32=self.flow32[lvl])
+            if lvl > 2:
+                nxt = self.x[lvl - 1]
+                o = BASE + self.nd + FEAT_C[lvl - 1]
+                # up_flow feeds the next level's concat (T) and its warp (fp32)
+                L[f"deconv{lvl}"].run_dgrad_form(self.flowT[lvl], nxt.slice(o, 2), y32=self.upflow32[lvl - 1], bias=True)
+                L[f"upfeat{lvl}"].run_dgrad_form(X, nxt.slice(o + 2, 2), bias=True)
+        # context network on the level-2 features, residual on flow2 (PWCNet.py:269-270)
+        src = self.x[2]
+        for i in range(6):
+            L[f"dc_conv{i + 1}"].run_fwd_form(src, self.dc[i], slope=SLOPE)
+            src = self.dc[i]
+        L["dc_conv7"].run_fwd_form(src, self.dc7)
+        f2 = self.flow32[2]
+        _lib.call("mireg_cast_to_f32", f2.ptr, f2.ld, self.dc7.ptr, self.dc7.ld, f2.rows, 2, 1.0, 1.0, code, st)
+        cast_from_f32(self.flowT[2], f2)
+        L["deconv2"].run_dgrad_form(self.flowT[2], self.flowT[1], y32=self.flow32[1], bias=True)
+        L["deconv1"].run_dgrad_form(self.flowT[1], None, y32=self.flow32[0], bias=True)
+        return [self.flow32[l].nchw() for l in range(0, 7)]
+
+    def backward(self, gflows) -> None:
+        raise NotImplementedError("PWCDCNet backward (correlation / warp backward kernels) is not implemented yet; "
+                                  "see DESIGN.md section 9")
+
+
+class PWCDCNet(nn.Module):
+    """Drop-in for PWC.models.PWCNet.PWCDCNet(md=4)."""
+
+    def __init__(self, md: int = 4, precision: str = "bf16"):
+        super().__init__()
+        self.md, self.precision = md, precision
+        for lvl, (cin, cout) in enumerate(PYRAMID, start=1):
+            n0, n1, n2 = PYR_NAMES[lvl]
+            setattr(self, n0, _conv(cin, cout, 3, 2))
+            setattr(self, n1, _conv(cout, cout, 3, 1))
+            setattr(self, n2, _conv(cout, cout, 3, 1))
+        self.corr = Correlation(pad_size=md, kernel_size=1, max_displacement=md, stride1=1, stride2=1, corr_multiply=1)
+        self.leakyRELU = nn.LeakyReLU(SLOPE)
+        nd = (2 * md + 1) ** 2
+        dd = np.cumsum(DENSE)
+        for lvl in (6, 5, 4, 3, 2):
+            od = nd if lvl == 6 else nd + FEAT_C[lvl] + 4
+            cin = od
+            for j, cout in enumerate(DENSE):
+                setattr(self, f"conv{lvl}_{j}", _conv(cin, cout))
+                cin = od + int(dd[j])
+            setattr(self, f"predict_flow{lvl}", nn.Conv2d(cin, 2, 3, 1, 1, bias=True))
+            if lvl > 2:
+                setattr(self, f"deconv{lvl}", nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True))
+                setattr(self, f"upfeat{lvl}", nn.ConvTranspose2d(cin, 2, 4, 2, 1, bias=True))
+        self.deconv2 = nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True)
+        self.deconv1 = nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True)
+        self.deconv0 = nn.ConvTranspose2d(2, 2, 4, 4, 0, bias=True)          # defined, unused (PWCNet.py:126,274)
+        cin = nd + 32 + 4 + int(dd[4])
+        for i, (cout, d) in enumerate(DC, start=1):
+            setattr(self, f"dc_conv{i}", _conv(cin, cout, 3, 1, d, d))
+            cin = cout
+        self.dc_conv7 = nn.Conv2d(32, 2, 3, 1, 1, bias=True)
+        for m in self.modules():  # PWCNet.py:136-140
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight.data, mode="fan_in")
+                if m.bias is not None:
+                    m.bias.data.zero_()
+        self._engines: Dict[tuple, PWCEngine] = {}
+
+    def engine_for(self, x: torch.Tensor) -> PWCEngine:
+        if not x.is_cuda:
+            raise RuntimeError("mireg.PWCDCNet runs on the MI355X only; there is no CPU fallback")
+        dtype = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        key = (tuple(x.shape), x.device, dtype, next(self.parameters()).data_ptr())
+        if key not in self._engines:
+            self._engines.clear()
+            B, C, H, W = x.shape
+            if C != 2:
+                raise RuntimeError(f"PWCDCNet expects (B,2,H,W) [fixed, moving], got {tuple(x.shape)}")
+            self._engines[key] = PWCEngine(self, B, H, W, x.device, dtype)
+        return self._engines[key]
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("PWCDCNet training (backward) is not implemented yet; wrap inference in "
+                                      "torch.no_grad() (DESIGN.md section 9)")
+        return tuple(self.engine_for(x).forward(x.float(), self.training))

@@ -1,0 +1,114 @@
+"""GPU parity: cost volume (K7/K8), PWC warp (K10), FlowNetC and PWC-DC-Net forward vs oracle / golden fixtures."""
+import pytest
+import torch
+
+from oracle import nets, ops as oops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("cfg", [(20, 2, 256, 32, 32, 2), (4, 1, 196, 4, 4, 3), (4, 1, 32, 64, 64, 2), (4, 1, 96, 16, 24, 1),
+                                 (20, 2, 8, 40, 72, 1)])
+def test_correlation_module_fp32(cfg):
+    """Drop-in Correlation module (NCHW fp32) vs the published-definition oracle (parity unpinned upstream)."""
+    import mireg
+    md, s2, C, H, W, B = cfg
+    f1 = nets.analytic_input((B, C, H, W), seed=1) - 0.5
+    f2 = nets.analytic_input((B, C, H, W), seed=2) - 0.5
+    want = oops.correlation(f1, f2, md, 1, md, 1, s2, 1)
+    got = mireg.Correlation(md, 1, md, 1, s2, 1)(f1.to(DEV), f2.to(DEV))
+    assert got.shape == want.shape
+    assert _rel(got, want) < 2e-5
+
+
+def test_correlation_bf16_views_with_lrelu():
+    from mireg.correlation import correlation_views
+    from mireg.engine import Workspace
+    ws = Workspace(torch.device(DEV), torch.bfloat16)
+    B, C, H, W, md, s2 = 2, 256, 32, 32, 20, 2
+    f1 = (nets.analytic_input((B, C, H, W), seed=1) - 0.5).bfloat16().float()
+    f2 = (nets.analytic_input((B, C, H, W), seed=2) - 0.5).bfloat16().float()
+    want = torch.nn.functional.leaky_relu(oops.correlation(f1, f2, md, 1, md, 1, s2, 1), 0.1)
+    v1, v2 = ws.new(B, H, W, C), ws.new(B, H, W, C)
+    v1.buf[..., :C] = f1.permute(0, 2, 3, 1).to(DEV)
+    v2.buf[..., :C] = f2.permute(0, 2, 3, 1).to(DEV)
+    out = ws.new(B, H, W, 473)
+    correlation_views(v1, v2, out.slice(32, 441), C, md, s2, 0.1, ws.code)
+    assert _rel(out.slice(32, 441).nchw().float(), want) < 1e-2
+    assert float(out.slice(0, 32).nchw().abs().max()) == 0.0      # neighbours of the slice untouched
+
+
+def test_pwc_warp_golden(golden):
+    from mireg.correlation import pwc_warp_views
+    from mireg.engine import Workspace
+    g = golden("g6_pwc_warp")
+    ws = Workspace(torch.device(DEV), torch.float32)
+    for (C, H) in ((128, 8), (64, 32), (32, 64)):
+        x = nets.analytic_input((2, C, H, H), seed=C)
+        flo = torch.from_numpy(g[f"flo_{C}_{H}"])
+        xv, ov = ws.new(2, H, H, C), ws.new(2, H, H, C)
+        xv.buf[..., :C] = x.permute(0, 2, 3, 1).to(DEV)
+        fv = ws.new(2, H, H, 2, dtype=torch.float32, pad=2)
+        fv.buf[...] = flo.permute(0, 2, 3, 1).to(DEV)
+        pwc_warp_views(xv, fv, 1.0, ov, ws.code)
+        got = ov.nchw().cpu()[:, ::8]
+        assert (got - torch.from_numpy(g[f"warp_{C}_{H}"])).abs().max().item() < 2e-5, (C, H)
+
+
+def test_pwcnet_fp32_golden(golden):
+    import mireg
+    g = golden("g5_skeletons")
+    m = mireg.PWCDCNet(md=4, precision="fp32")
+    nets.analytic_weights_(m)
+    m = m.to(DEV).eval()
+    x = nets.analytic_input((1, 2, 256, 256), seed=8).to(DEV)
+    with torch.no_grad():
+        flows = m(x)
+    assert [tuple(f.shape[2:]) for f in flows] == [(256, 256), (128, 128), (64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
+    for i, f in enumerate(flows):
+        want = torch.from_numpy(g[f"pwc_flow{i}"])
+        got = f.cpu() if f.shape[-1] <= 64 else f.cpu()[:, :, ::4, ::4]
+        err, scale = (got - want).abs().max().item(), want.abs().max().item()
+        assert err <= 2e-4 * max(1.0, scale), (i, err, scale)
+    assert list(m.state_dict().keys()) == list(nets.PWCDCNet().state_dict().keys())
+
+
+def test_flownetc_fp32_golden(golden):
+    import mireg
+    g = golden("g5_skeletons")
+    m = mireg.FlowNetC(None, batchNorm=True, precision="fp32")
+    nets.analytic_weights_(m)
+    m = m.to(DEV)
+    x = nets.analytic_input((2, 2, 256, 256), seed=9).to(DEV)
+    for mode in ("train", "eval"):
+        m.train(mode == "train")
+        with torch.no_grad():
+            flows = m(x)
+        assert len(flows) == (5 if mode == "train" else 1)
+        for i, f in enumerate(flows):
+            want = torch.from_numpy(g[f"flownetc_{mode}_flow{i}"])
+            err, scale = (f.cpu() - want).abs().max().item(), want.abs().max().item()
+            assert err <= 5e-4 * max(1.0, scale), (mode, i, err, scale)
+    sd_keys = [k for k in nets.FlowNetC().state_dict().keys()]
+    assert [k for k in m.state_dict().keys()] == sd_keys
+
+
+def test_pwc_bf16_close_and_registration_wrapper():
+    import mireg
+    torch.manual_seed(0)
+    reg32 = mireg.opticalFlowReg("pwc", precision="fp32").to(DEV).eval()
+    reg16 = mireg.opticalFlowReg("pwc", precision="bf16").to(DEV).eval()
+    reg16.load_state_dict(reg32.state_dict())
+    x = nets.analytic_input((2, 2, 256, 256), seed=4).to(DEV)
+    with torch.no_grad():
+        f32, w32, _, _ = reg32(x)
+        f16, w16, _, _ = reg16(x)
+    assert len(f32) == 7 and len(w32) == 7
+    for a, b in zip(f32[:3], f16[:3]):
+        assert ((a - b).double().norm() / a.double().norm().clamp_min(1e-9)).item() < 8e-2
