@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import dist as mdist
 from .engine import AdamJob, F32, _stream, upload_table
 
 
@@ -153,7 +154,7 @@ class RegistrationTrainer:
         self.loss.forward(self.x_static, flows)
         Bg = self.loss.B * self.world if self.sync_loss_stats else None
         if self.sync_loss_stats:
-            torch.distributed.all_reduce(self.loss.sums, group=self.pg)
+            mdist.all_reduce_loss_moments_(self.loss.sums, self.pg)
         self.loss.finalize(Bg)
         gflows = self.loss.backward(flows, Bg)
         self.eng.backward(gflows)
@@ -173,13 +174,11 @@ class RegistrationTrainer:
             if self._graph_fb is None:
                 self._capture()
             self._graph_fb.replay()
-            if self.world > 1:
-                torch.distributed.all_reduce(self.flat_g, group=self.pg)
+            mdist.all_reduce_gradients_(self.flat_g, self.pg)
             self._graph_opt.replay()
         else:
             self._fwd_bwd()
-            if self.world > 1:
-                torch.distributed.all_reduce(self.flat_g, group=self.pg)
+            mdist.all_reduce_gradients_(self.flat_g, self.pg)
             self._optim()
             self._warm += 1
         return self.loss.out4
