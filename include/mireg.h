@@ -95,6 +95,10 @@ int mireg_dice(const float* y_true, const float* y_pred, float* counts, float* d
  * mireg_conv_wgrad reuses the struct: y/y_ld = dy rows over the same logical grid with N = Cout
  * channels, x = the forward input; result slab[split_k][N][taps*x_C] (fp32).
  * x_C, x_ld, w_ld, y_ld (wgrad) must be multiples of 8 (bf16) / 4 (fp32); pad channels must hold zeros. */
+typedef struct mireg_conv_cls {     /* one output-pixel parity class of a stride-2 DGRAD-form launch */
+  int taps_y, taps_x, off_y, off_x, g_H, g_W, y_off_y, y_off_x;
+  const void* w; long w_ld, w_bytes;
+} mireg_conv_cls;
 typedef struct mireg_conv_desc {
   const void* x; long x_ld; int x_H, x_W, x_C;
   int taps_y, taps_x;
@@ -106,7 +110,11 @@ typedef struct mireg_conv_desc {
   const float* bias; float slope; int accumulate; int dtype;
   int split_k; float* slab;
   long x_bytes, w_bytes;   /* readable bytes from x / w to the end of their allocations (buffer descriptors of the
-                              LDS-DMA tile loads; 0 selects the register-staged kernel) */
+                              LDS-DMA tile loads, each < 2 GiB) */
+  int n_cls;               /* 0/1: the fields above describe the launch; 2..4: blockIdx.y picks cls[] (taps, offsets,
+                              sub-grid, output offset and weights per parity class), everything else is shared */
+  mireg_conv_cls cls[4];
+  long slab_cls_stride;    /* floats between the split-K slabs of consecutive classes */
 } mireg_conv_desc;
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream);
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);

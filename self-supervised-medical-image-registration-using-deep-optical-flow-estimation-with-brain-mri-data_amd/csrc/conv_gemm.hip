@@ -58,192 +58,8 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
 
 // =====================================================================================================
-// FWD / DGRAD: C[m][n] = sum_k A[m][k] * W[n][k], rows m = output pixels (gathered), cols n = channels
-// =====================================================================================================
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256)
-conv_gemm_kernel(const mireg_conv_desc p) {
-  constexpr int CPC = Cfg<T>::CPC, BK = Cfg<T>::BK;
-  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-  constexpr int A_CH = BM / 64;
-  constexpr int B_CH = (BN + 63) / 64;
-  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "bad tile");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * kRowB];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
-  const int r = lane & 31, h = lane >> 5;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int gHW = p.g_H * p.g_W;
-  const int M = p.n_img * gHW;
-  const int K = p.taps_y * p.taps_x * p.x_C;
-  const int nk_total = (K + BK - 1) / BK;
-  int kt_begin = 0, kt_end = nk_total;
-  if (p.split_k > 1) {
-    const int per = (nk_total + p.split_k - 1) / p.split_k;
-    kt_begin = blockIdx.z * per;
-    kt_end = min(nk_total, kt_begin + per);
-  }
-
-  // ---- loader state ---------------------------------------------------------------------------
-  const int kc = tid & 3, lrow = tid >> 2;
-  long a_base[A_CH];
-  int a_iy0[A_CH], a_ix0[A_CH];
-  bool a_ok[A_CH];
-#pragma unroll
-  for (int c = 0; c < A_CH; ++c) {
-    const int m = m0 + lrow + 64 * c;
-    a_ok[c] = m < M;
-    const int mm = a_ok[c] ? m : 0;
-    const int img = mm / gHW, rem = mm - img * gHW;
-    const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
-    a_base[c] = (long)img * p.x_H * p.x_W * p.x_ld;
-    a_iy0[c] = gy * p.mul_y + p.off_y;
-    a_ix0[c] = gx * p.mul_x + p.off_x;
-  }
-  const int cpt = p.x_C / CPC;              // chunks per tap
-  int ty, tx, cc;
-  {
-    const int q = kt_begin * 4 + kc;
-    const int tap = q / cpt;
-    cc = q - tap * cpt;
-    ty = tap / p.taps_x;
-    tx = tap - ty * p.taps_x;
-  }
-  const T* __restrict__ xp = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ wp = reinterpret_cast<const T*>(p.w);
-  Chunk ra[A_CH], rb[B_CH];
-  const Chunk zero = {{0u, 0u, 0u, 0u}};
-
-  auto load_tiles = [&](int kt) {
-    const bool kvalid = ty < p.taps_y;
-#pragma unroll
-    for (int c = 0; c < A_CH; ++c) {
-      const int iy = a_iy0[c] + ty * p.step_y, ix = a_ix0[c] + tx * p.step_x;
-      const bool ok = a_ok[c] && kvalid && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
-      ra[c] = ok ? ldg_chunk(xp + a_base[c] + ((long)iy * p.x_W + ix) * p.x_ld + cc * CPC) : zero;
-    }
-    const int k = kt * BK + kc * CPC;
-#pragma unroll
-    for (int c = 0; c < B_CH; ++c) {
-      const int nl = lrow + 64 * c, n = n0 + nl;
-      const bool ok = nl < BN && n < p.N && k < K;
-      rb[c] = ok ? ldg_chunk(wp + (long)n * p.w_ld + k) : zero;
-    }
-    cc += 4;                                 // advance this thread's chunk by one K-step
-    while (cc >= cpt) { cc -= cpt; if (++tx == p.taps_x) { tx = 0; ++ty; } }
-  };
-  auto store_tiles = [&](int buf) {
-    unsigned char* As = smem + buf * (BM + BN) * kRowB;
-    unsigned char* Bs = As + BM * kRowB;
-#pragma unroll
-    for (int c = 0; c < A_CH; ++c) *reinterpret_cast<Chunk*>(As + (lrow + 64 * c) * kRowB + kc * 16) = ra[c];
-#pragma unroll
-    for (int c = 0; c < B_CH; ++c)
-      if (lrow + 64 * c < BN) *reinterpret_cast<Chunk*>(Bs + (lrow + 64 * c) * kRowB + kc * 16) = rb[c];
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  if (kt_begin < kt_end) {
-    load_tiles(kt_begin);
-    store_tiles(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const bool more = kt + 1 < kt_end;
-      if (more) load_tiles(kt + 1);
-      const unsigned char* As = smem + cur * (BM + BN) * kRowB + (wm * WTM + r) * kRowB;
-      const unsigned char* Bs = smem + cur * (BM + BN) * kRowB + BM * kRowB + (wn * WTN + r) * kRowB;
-      if constexpr (sizeof(T) == 2) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 af[TM], bfr[TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * kRowB + ks * 32 + h * 16);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * kRowB + ks * 32 + h * 16);
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-      } else {
-        // fp32 operands: lane (r,h) takes K slots {8g+4h .. 8g+4h+3}; MFMA t of group g contracts slot t of
-        // both halves -- the same K permutation on A and B, so the sum over K is unchanged.
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          f32x4 af[TM], bfr[TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * kRowB + g * 32 + h * 16);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * kRowB + g * 32 + h * 16);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bfr[j][t], acc[i][j], 0, 0, 0);
-        }
-      }
-      if (more) store_tiles(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
-    }
-  }
-
-  // ---- epilogue ---------------------------------------------------------------------------------
-  // 32x32 accumulator: column n = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-  T* __restrict__ yp = reinterpret_cast<T*>(p.y);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (m >= M) continue;
-      if (p.split_k > 1) {
-        float* dst = p.slab + ((long)blockIdx.z * M + m) * p.N;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn * WTN + j * 32 + r;
-          if (n < p.N) dst[n] = acc[i][j][e];
-        }
-        continue;
-      }
-      const int img = m / gHW, rem = m - img * gHW;
-      const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
-      const long pix = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + r;
-        if (n >= p.N) continue;
-        float v = acc[i][j][e];
-        if (p.bias) v += p.bias[n];
-        v = v > 0.f ? v : v * p.slope;
-        if (yp) {
-          T* d = yp + pix * p.y_ld + n;
-          if (p.accumulate) v += to_f32(*d);
-          *d = from_f32<T>(v);
-        }
-        if (p.y32) p.y32[pix * p.y32_ld + n] = v;
-      }
-    }
-  }
-}
-
-
-// =====================================================================================================
-// v2 of the same contraction: LDS-DMA ring.  Tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 16 B per
+// FWD / DGRAD: C[m][n] = sum_k A[m][k] * W[n][k], rows m = output pixels (gathered), cols n = channels.
+// LDS-DMA ring.  Tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 16 B per
 // lane, 1 KiB per wave-instruction) into a 4-stage ring, so three K-steps of loads are always in flight behind
 // the MFMAs; one raw s_barrier per K-step, counted s_waitcnt vmcnt(N) (never 0 in steady state).
 //   * zero padding / tile tails: the lane's buffer offset is pushed out of range, the hardware writes zeros;
@@ -269,7 +85,7 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(256)
-conv_gemm_dma_kernel(const mireg_conv_desc p) {
+conv_gemm_dma_kernel(const mireg_conv_desc pd) {
   constexpr int CPC = Cfg<T>::CPC, BK = Cfg<T>::BK;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   constexpr int STAGES = 4;
@@ -282,11 +98,24 @@ conv_gemm_dma_kernel(const mireg_conv_desc p) {
   constexpr int SMEM_BYTES = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
 
+  // stride-2 backward-data / deconvolution: blockIdx.y selects the output-pixel parity class (own taps, weights,
+  // sub-grid and output offset); one launch covers all classes so the deep layers still fill the chip
+  mireg_conv_desc p = pd;
+  const int cls = blockIdx.y;
+  if (pd.n_cls > 1) {
+    const mireg_conv_cls k = pd.cls[cls];
+    p.taps_y = k.taps_y; p.taps_x = k.taps_x; p.off_y = k.off_y; p.off_x = k.off_x; p.g_H = k.g_H; p.g_W = k.g_W;
+    p.y_off_y = k.y_off_y; p.y_off_x = k.y_off_x; p.w = k.w; p.w_ld = k.w_ld; p.w_bytes = k.w_bytes;
+  }
+
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
   const int r = lane & 31, h = lane >> 5;
   const int tiles_n = (p.N + BN - 1) / BN;
+  const int gHW = p.g_H * p.g_W;
+  const int M = p.n_img * gHW;
+  const int my_tiles = ((M + BM - 1) / BM) * tiles_n;
   // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so give each XCD a contiguous
   // run of tiles (neighbouring m-tiles x all n-tiles): its 4 MiB L2 then holds that run's pixels and the weights.
   int bid = blockIdx.x;
@@ -294,10 +123,9 @@ conv_gemm_dma_kernel(const mireg_conv_desc p) {
     const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
   }
+  if (bid >= my_tiles) return;                                      // classes with fewer tiles than the grid
   const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int gHW = p.g_H * p.g_W;
-  const int M = p.n_img * gHW;
   const int K = p.taps_y * p.taps_x * p.x_C;
   const int nk_total = (K + BK - 1) / BK;
   int kt_begin = 0, kt_end = nk_total;
@@ -306,6 +134,7 @@ conv_gemm_dma_kernel(const mireg_conv_desc p) {
     kt_begin = blockIdx.z * per;
     kt_end = min(nk_total, kt_begin + per);
   }
+  float* const slab_base = p.slab ? p.slab + (long)cls * pd.slab_cls_stride : nullptr;
 
   // ---- DMA source state: lane L of a group covers row L>>2, physical chunk L&3 = logical chunk ^ swizzle ----
   constexpr unsigned kOOB = 0x80000000u;
@@ -509,7 +338,7 @@ conv_gemm_dma_kernel(const mireg_conv_desc p) {
       const long off = rowoff[ml];
       if (off < 0 || n >= p.N) continue;
       const float4 v = *reinterpret_cast<const float4*>(ct + ml * BN + nl);
-      float* d = p.slab + off + n;
+      float* d = slab_base + off + n;
       if (vec) stg_u4(d, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
       else { const float vv[4] = {v.x, v.y, v.z, v.w}; for (int q = 0; q < 4 && n + q < p.N; ++q) d[q] = vv[q]; }
     }
@@ -571,15 +400,48 @@ conv_gemm_dma_kernel(const mireg_conv_desc p) {
 // split-K second pass: y = act(sum_z slab[z] + bias) with the same pixel mapping as the main epilogue
 template <typename T>
 __global__ void __launch_bounds__(256)
-splitk_reduce_kernel(const mireg_conv_desc p) {
+splitk_reduce_kernel(const mireg_conv_desc pd) {
+  mireg_conv_desc p = pd;
+  if (pd.n_cls > 1) {
+    const mireg_conv_cls k = pd.cls[blockIdx.y];
+    p.g_H = k.g_H; p.g_W = k.g_W; p.y_off_y = k.y_off_y; p.y_off_x = k.y_off_x;
+  }
+  const float* __restrict__ slab = p.slab + (long)blockIdx.y * pd.slab_cls_stride;
   const int gHW = p.g_H * p.g_W;
   const long M = (long)p.n_img * gHW, total = M * p.N;
   T* __restrict__ yp = reinterpret_cast<T*>(p.y);
+  const bool vec = (p.N % 4) == 0 && yp && (p.y_ld % 4) == 0 && !p.y32;
+  if (vec) {                                                        // 4 channels per thread: 16-B slab reads
+    const int n4 = p.N >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M * n4; i += (long)gridDim.x * blockDim.x) {
+      const long m = i / n4;
+      const int n = (int)(i - m * n4) * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < p.split_k; ++z) {
+        const Chunk c = ldg_chunk(slab + (long)z * total + m * p.N + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += __uint_as_float(c.w[q]);
+      }
+      const int img = (int)(m / gHW), rem = (int)(m - (long)img * gHW);
+      const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
+      const long pix = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
+      T* d = yp + pix * p.y_ld + n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float vv = v[q];
+        if (p.bias) vv += p.bias[n + q];
+        vv = vv > 0.f ? vv : vv * p.slope;
+        if (p.accumulate & 1) vv += to_f32(d[q]);
+        d[q] = from_f32<T>(vv);
+      }
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / p.N;
     const int n = (int)(i - m * p.N);
     float v = 0.f;
-    for (int z = 0; z < p.split_k; ++z) v += p.slab[(long)z * total + i];
+    for (int z = 0; z < p.split_k; ++z) v += slab[(long)z * total + i];
     if (p.bias) v += p.bias[n];
     v = v > 0.f ? v : v * p.slope;
     const int img = (int)(m / gHW), rem = (int)(m - (long)img * gHW);
@@ -768,34 +630,31 @@ conv_wgrad_kernel(const mireg_conv_desc p) {
     }
 }
 
-bool use_v1() {
-  static const int v = [] { const char* e = getenv("MIREG_GEMM_V1"); return (e && e[0] == '1') ? 1 : 0; }();
-  return v != 0;
-}
-
 template <typename T>
 int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
-  const long M = (long)p.n_img * p.g_H * p.g_W;
+  const int ncls = p.n_cls > 1 ? p.n_cls : 1;
+  long M = 0;                                                       // largest class decides the grid
+  for (int c = 0; c < ncls; ++c) {
+    const long m = ncls > 1 ? (long)p.n_img * p.cls[c].g_H * p.cls[c].g_W : (long)p.n_img * p.g_H * p.g_W;
+    M = m > M ? m : M;
+  }
   const int z = p.split_k > 1 ? p.split_k : 1;
-  const bool dma = !use_v1() && p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < (1L << 31) && p.w_bytes < (1L << 31);
   if (p.N > 64) {
-    dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 127) / 128)), 1, z);
-    if (dma) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, stream, p);
+    dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 127) / 128)), ncls, z);
+    hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, stream, p);
   } else if (p.N > 32) {
-    dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 63) / 64)), 1, z);
-    if (dma) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, stream, p);
+    dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 63) / 64)), ncls, z);
+    hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, stream, p);
   } else {
-    dim3 grid((unsigned)((M + 127) / 128), 1, z);
-    if (dma) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 32, 4, 1>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1>), grid, dim3(256), 0, stream, p);
+    dim3 grid((unsigned)((M + 127) / 128), ncls, z);
+    hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 32, 4, 1>), grid, dim3(256), 0, stream, p);
   }
   if (z > 1) {
     const long total = M * p.N;
-    long g = (total + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)g), dim3(256), 0, stream, p);
+    long g = (total / 4 + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)g, ncls), dim3(256), 0, stream, p);
   }
   return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
 }
@@ -820,7 +679,11 @@ bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
   if (wgrad) {
     if (!p->y || !p->slab || p->y_ld % cpc || ((uintptr_t)p->y % 16)) return false;
   } else {
-    if (!p->w || p->w_ld % cpc || ((uintptr_t)p->w % 16)) return false;
+    if (p->n_cls < 0 || p->n_cls > 4) return false;
+    if (p->n_cls <= 1 && (!p->w || p->w_ld % cpc || ((uintptr_t)p->w % 16) || p->w_bytes <= 0 || p->w_bytes >= (1L << 31))) return false;
+    if (p->x_bytes <= 0 || p->x_bytes >= (1L << 31)) return false;
+    for (int c = 0; c < (p->n_cls > 1 ? p->n_cls : 0); ++c)
+      if (!p->cls[c].w || p->cls[c].w_ld % cpc || ((uintptr_t)p->cls[c].w % 16) || p->cls[c].w_bytes <= 0 || p->cls[c].w_bytes >= (1L << 31) || p->cls[c].g_H <= 0 || p->cls[c].g_W <= 0 || p->cls[c].taps_y <= 0 || p->cls[c].taps_x <= 0) return false;
     if (!p->y && !p->y32) return false;
     if (p->split_k > 1 && !p->slab) return false;
   }

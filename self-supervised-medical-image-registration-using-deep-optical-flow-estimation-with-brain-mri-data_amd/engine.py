@@ -28,6 +28,12 @@ def rup(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
+class ConvCls(ctypes.Structure):
+    _fields_ = [("taps_y", ctypes.c_int), ("taps_x", ctypes.c_int), ("off_y", ctypes.c_int), ("off_x", ctypes.c_int),
+                ("g_H", ctypes.c_int), ("g_W", ctypes.c_int), ("y_off_y", ctypes.c_int), ("y_off_x", ctypes.c_int),
+                ("w", ctypes.c_void_p), ("w_ld", ctypes.c_long), ("w_bytes", ctypes.c_long)]
+
+
 class ConvDesc(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("x_ld", ctypes.c_long), ("x_H", ctypes.c_int), ("x_W", ctypes.c_int),
                 ("x_C", ctypes.c_int), ("taps_y", ctypes.c_int), ("taps_x", ctypes.c_int),
@@ -39,7 +45,8 @@ class ConvDesc(ctypes.Structure):
                 ("y_mul_y", ctypes.c_int), ("y_mul_x", ctypes.c_int), ("y_off_y", ctypes.c_int), ("y_off_x", ctypes.c_int),
                 ("y32", ctypes.c_void_p), ("y32_ld", ctypes.c_long),
                 ("bias", ctypes.c_void_p), ("slope", ctypes.c_float), ("accumulate", ctypes.c_int), ("dtype", ctypes.c_int),
-                ("split_k", ctypes.c_int), ("slab", ctypes.c_void_p), ("x_bytes", ctypes.c_long), ("w_bytes", ctypes.c_long)]
+                ("split_k", ctypes.c_int), ("slab", ctypes.c_void_p), ("x_bytes", ctypes.c_long), ("w_bytes", ctypes.c_long),
+                ("n_cls", ctypes.c_int), ("cls", ConvCls * 4), ("slab_cls_stride", ctypes.c_long)]
 
 
 class PackClass(ctypes.Structure):
@@ -251,15 +258,17 @@ class ConvLayer:
         return j
 
     # ---- launches -----------------------------------------------------------------------------
-    def _finish(self, d: ConvDesc, M: int, N: int, K: int, allow_split: bool) -> None:
+    def _finish(self, d: ConvDesc, M: int, N: int, K: int, allow_split: bool, ncls: int = 1) -> None:
+        """M = rows of the largest class, K = smallest class K (bounds the split)."""
         bk = 32 if self.ws.code == DT_BF16 else 16
         bn = 128 if N > 64 else (64 if N > 32 else 32)
-        tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
+        tiles = ((M + 127) // 128) * ((N + bn - 1) // bn) * ncls
         nk = (K + bk - 1) // bk
         split = _split_for(tiles, nk) if allow_split else 1
         d.split_k = split
         if split > 1:
-            self.ws.need_scratch(split * M * N)
+            d.slab_cls_stride = split * M * N
+            self.ws.need_scratch(ncls * split * M * N)
             d.slab = self.ws.get_scratch().data_ptr()
         d.dtype = self.ws.code
 
@@ -306,31 +315,41 @@ class ConvLayer:
         (only exact divisions contribute).  out has the LARGER spatial size."""
         assert g.C <= self.Cop and g.c0 + self.Cop <= g.ld, (self.name, g.C, self.Co, g.ld)
         o = out if out is not None else y32
+        live = []
         for c in self.classes:
             gH = (o.H - c["py"] + self.s - 1) // self.s
             gW = (o.W - c["px"] + self.s - 1) // self.s
-            if gH <= 0 or gW <= 0:
-                continue
-            assert c["K"] > 0, "kernel smaller than stride is not supported"
-            d = ConvDesc()
-            d.x, d.x_ld, d.x_H, d.x_W, d.x_C = g.ptr, g.ld, g.H, g.W, self.Cop
-            d.taps_y, d.taps_x = c["nty"], c["ntx"]
-            d.mul_y = d.mul_x = 1
-            if self.s == 1:
-                d.off_y = d.off_x = self.p
-                d.step_y = d.step_x = -self.d
-            else:
-                d.off_y, d.off_x = c["cy"], c["cx"]
-                d.step_y = d.step_x = -1
-            d.g_H, d.g_W, d.n_img = gH, gW, g.B
-            d.w, d.w_ld, d.N = c["pack"].data_ptr(), c["pack"].shape[1], self.Ci
-            d.x_bytes, d.w_bytes = g.bytes_left, c["pack"].numel() * c["pack"].element_size()
-            self._fill_out(d, out, y32, o.H, o.W, self.s, self.s, c["py"], c["px"])
-            d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
-            d.slope, d.accumulate = slope, int(accumulate)
-            self._finish(d, g.B * gH * gW, self.Ci, c["K"], True)
-            PROFILER.launch("mireg_conv_gemm", d, self._family(self.Ci, d.split_k),
-                            2.0 * g.B * gH * gW * self.Ci * c["nty"] * c["ntx"] * self.Co)
+            if gH > 0 and gW > 0:
+                assert c["K"] > 0, "kernel smaller than stride is not supported"
+                live.append((c, gH, gW))
+        d = ConvDesc()
+        d.x, d.x_ld, d.x_H, d.x_W, d.x_C = g.ptr, g.ld, g.H, g.W, self.Cop
+        d.x_bytes = g.bytes_left
+        d.mul_y = d.mul_x = 1
+        d.step_y = d.step_x = -self.d if self.s == 1 else -1
+        d.n_img, d.N = g.B, self.Ci
+        d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
+        d.slope, d.accumulate = slope, int(accumulate)
+        flops = 0.0
+        for i, (c, gH, gW) in enumerate(live):
+            k = ConvCls()
+            k.taps_y, k.taps_x = c["nty"], c["ntx"]
+            k.off_y, k.off_x = (self.p, self.p) if self.s == 1 else (c["cy"], c["cx"])
+            k.g_H, k.g_W, k.y_off_y, k.y_off_x = gH, gW, c["py"], c["px"]
+            k.w, k.w_ld, k.w_bytes = c["pack"].data_ptr(), c["pack"].shape[1], c["pack"].numel() * c["pack"].element_size()
+            d.cls[i] = k
+            flops += 2.0 * g.B * gH * gW * self.Ci * c["nty"] * c["ntx"] * self.Co
+        c0, gH0, gW0 = live[0]
+        # class 0 mirrored in the top-level fields (single-class launches read only those)
+        d.taps_y, d.taps_x, d.off_y, d.off_x = d.cls[0].taps_y, d.cls[0].taps_x, d.cls[0].off_y, d.cls[0].off_x
+        d.g_H, d.g_W = gH0, gW0
+        d.w, d.w_ld, d.w_bytes = d.cls[0].w, d.cls[0].w_ld, d.cls[0].w_bytes
+        self._fill_out(d, out, y32, o.H, o.W, self.s, self.s, c0["py"], c0["px"])
+        d.n_cls = len(live) if len(live) > 1 else 0
+        Mmax = max(g.B * gh * gw for _, gh, gw in live)
+        Kmin = min(c["K"] for c, _, _ in live)
+        self._finish(d, Mmax, self.Ci, Kmin, True, len(live))
+        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Ci, d.split_k), flops)
 
     def plan_wgrad(self, x: View, dy: View) -> None:
         """Size the persistent split-K slab for dW[co][(ky,kx,ci_pad)] = sum_pix dy[pix][co] x[pix@tap][ci]."""

@@ -51,6 +51,27 @@ class PredictorEngineBase:
         self.layers[name] = lay
         return lay
 
+    # -- backward-weights on a side stream ---------------------------------------------------------------
+    # wgrad(L) and dgrad(L) are independent and each alone under-fills 256 CUs on the deep layers, so wgrad is
+    # forked onto a second HIP stream (captured as a parallel hipGraph branch) and joined before the unpack.
+    use_side_stream = True
+
+    def wgrad_async(self, lay: ConvLayer, x: View, dy: View) -> None:
+        if not self.use_side_stream:
+            lay.run_wgrad(x, dy)
+            return
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.ws.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            lay.run_wgrad(x, dy)
+
+    def join_side(self) -> None:
+        if getattr(self, "_side", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def pack_weights(self) -> None:
         """torch-layout fp32 parameters -> GEMM packs (one table-driven launch)."""
         key = tuple(l.weight.data_ptr() for l in self.layers.values())
@@ -239,7 +260,7 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
         # ---- decoder, fine -> coarse ---------------------------------------------------------------
         load_loss_grad(2)
         pf = L["predict_flow2"]
-        pf.run_wgrad(c[2], self.dflowT[2])
+        self.wgrad_async(pf, c[2], self.dflowT[2])
         pf.run_bias_grad(self.dflowT[2])
         pf.run_dgrad_form(self.dflowT[2], dc[2])                              # dcat2 <- (beta 0)
         for lvl in (2, 3, 4, 5):
@@ -250,18 +271,18 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
             gup = dc[lvl].slice(cs + cd, 2)
             up = L[f"up{lvl + 1}"]
             load_loss_grad(lvl + 1)                                           # dflowT[lvl+1] <- loss grad
-            up.run_wgrad(gup, self.flowT[lvl + 1])
+            self.wgrad_async(up, gup, self.flowT[lvl + 1])
             up.run_bias_grad(gup)
             up.run_fwd_form(gup, self.dflowT[lvl + 1], bias=False, accumulate=True)
             # feature deconv (lvl+1 -> lvl) + LeakyReLU
             gde = dc[lvl].slice(cs, cd)
             lrelu_bwd(gde, c[lvl].slice(cs, cd), SLOPE, self.ws)
             de = L[f"deconv{lvl}"]
-            de.run_wgrad(gde, feat_prev)
+            self.wgrad_async(de, gde, feat_prev)
             de.run_bias_grad(gde)
             # predict_flow{lvl+1} writes dfeat_prev first (beta 0), the deconv then accumulates into it
             pfn = L[f"predict_flow{lvl + 1}"]
-            pfn.run_wgrad(feat_prev, self.dflowT[lvl + 1])
+            self.wgrad_async(pfn, feat_prev, self.dflowT[lvl + 1])
             pfn.run_bias_grad(self.dflowT[lvl + 1])
             pfn.run_dgrad_form(self.dflowT[lvl + 1], dfeat_prev)
             de.run_fwd_form(gde, dfeat_prev, bias=False, accumulate=True)
@@ -277,9 +298,10 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
                 lrelu_bwd(ddst, dst, SLOPE, self.ws)
                 dy = ddst
                 lay.run_bias_grad(dy)
-            lay.run_wgrad(src, dy)
+            self.wgrad_async(lay, src, dy)
             if dsrc is not None:
                 lay.run_dgrad_form(dy, dsrc, accumulate=acc)
+        self.join_side()
         self.unpack_grads()
 
 
