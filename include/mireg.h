@@ -93,7 +93,7 @@ int mireg_dice(const float* y_true, const float* y_pred, float* counts, float* d
  * image; y (dtype `dtype`) and/or y32 (fp32) receive act(acc + bias) [+ previous y if accumulate].
  * split_k > 1: partial sums go to slab[split_k][M][N] (fp32) and a second pass finishes.
  * mireg_conv_wgrad reuses the struct: y/y_ld = dy rows over the same logical grid with N = Cout
- * channels, x = the forward input; result slab[split_k][N][taps*x_C] (fp32).
+ * channels, x = the forward input, w_bytes = readable bytes of dy; result slab[split_k][N][taps*x_C] (fp32).
  * x_C, x_ld, w_ld, y_ld (wgrad) must be multiples of 8 (bf16) / 4 (fp32); pad channels must hold zeros. */
 typedef struct mireg_conv_cls {     /* one output-pixel parity class of a stride-2 DGRAD-form launch */
   int taps_y, taps_x, off_y, off_x, g_H, g_W, y_off_y, y_off_x;
@@ -147,7 +147,7 @@ int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, int total_unit
 /* y = raw convolution output [M][ld_y]; out = lrelu(bn(y)); ss = [scale | shift | mean | rstd] (4*C floats,
  * kept for the backward pass); partial = workspace of MIREG_BN_MAX_BLOCKS * 2 * C floats (two-stage,
  * deterministic reduction); running stats are updated in place when training (momentum, unbiased var). */
-#define MIREG_BN_MAX_BLOCKS 1024
+#define MIREG_BN_MAX_BLOCKS 512
 int mireg_bn_forward(const void* y, long ld_y, void* out, long ld_o, long M, int C, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                      int training, float slope, float* partial, float* ss, int dtype, hipStream_t stream);

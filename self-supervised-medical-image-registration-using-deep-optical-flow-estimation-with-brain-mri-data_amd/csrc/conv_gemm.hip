@@ -630,6 +630,209 @@ conv_wgrad_kernel(const mireg_conv_desc p) {
     }
 }
 
+// =====================================================================================================
+// WGRAD on the LDS-DMA ring: dW[co][kidx] = sum_pix dy[pix][co] * x[gather(pix, tap(kidx))][c(kidx)]
+// Both operand tiles are [pixel][128 channels] (channel-contiguous in HBM), filled by buffer_load ... lds
+// (bf16: one DMA = 4 pixel rows x 256 B; fp32: 2 rows x 512 B) into a 4-stage ring.  bf16 fragments come from
+// the transposing read ds_read_b64_tr_b16; its 4 rows-per-lane-group would hit the same banks on 256-B rows, so
+// 16-B chunks are XOR-swizzled with (pixel_row & 3) << 2 on the DMA source side and on the read side.
+// =====================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv_wgrad_dma_kernel(const mireg_conv_desc p) {
+  constexpr int CPC = Cfg<T>::CPC, BK = Cfg<T>::BK, BM = 128, BN = 128;
+  constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2;
+  constexpr int STAGES = 4;
+  constexpr int ROWB = 128 * (int)sizeof(T);                     // bytes per pixel row of a tile
+  constexpr int RPI = 1024 / ROWB;                               // pixel rows per DMA instruction (4 bf16 / 2 fp32)
+  constexpr int CPR = ROWB / 16;                                 // 16-B chunks per row (16 / 32)
+  constexpr int TILE_BYTES = BK * ROWB;                          // 8 KiB
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int EPI_BYTES = BM * BN * 4;
+  constexpr int SMEM_BYTES = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
+  constexpr int INSTR = TILE_BYTES / 1024;                       // 8 DMA instructions per tile, 2 per wave
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int Ktot = p.taps_y * p.taps_x * p.x_C;                  // GEMM N
+  const int tiles_n = (Ktot + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int gHW = p.g_H * p.g_W;
+  const int P = p.n_img * gHW;                                   // reduction length (pixels)
+  const int nk_total = (P + BK - 1) / BK;
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.split_k > 1) {
+    const int per = (nk_total + p.split_k - 1) / p.split_k;
+    kt_begin = blockIdx.z * per;
+    kt_end = min(nk_total, kt_begin + per);
+  }
+  constexpr unsigned kOOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.y), 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+  // lane -> (row inside the DMA instruction, logical 16-B chunk); bf16 rows are swizzled by (row & 3) << 2
+  const int lrow = lane / CPR, pch = lane % CPR;
+  const int lch = sizeof(T) == 2 ? (pch ^ ((lrow & 3) << 2)) : pch;
+  // A operand (dy): column part of the offset is fixed per lane
+  const int a_col = m0 + lch * CPC;
+  const bool a_cok = a_col < (p.N + CPC - 1) / CPC * CPC;
+  // B operand (x): the lane's kidx chunk fixes (tap, channel)
+  const int b_n = n0 + lch * CPC;
+  const bool b_cok = b_n < Ktot;
+  const int b_tap = (b_cok ? b_n : 0) / p.x_C, b_ch = (b_cok ? b_n : 0) - b_tap * p.x_C;
+  const int b_ty = b_tap / p.taps_x, b_tx = b_tap - b_ty * p.taps_x;
+  const int b_dy = p.off_y + b_ty * p.step_y, b_dx = p.off_x + b_tx * p.step_x;
+
+  // this lane's pixel for its two DMA instructions, kept decomposed (img, gy, gx) and advanced by BK per K-step
+  int pix[2], p_img[2], p_gy[2], p_gx[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    pix[c] = kt_begin * BK + (wid + 4 * c) * RPI + lrow;
+    const int pp = min(pix[c], P - 1);
+    p_img[c] = pp / gHW;
+    const int rem = pp - p_img[c] * gHW;
+    p_gy[c] = rem / p.g_W;
+    p_gx[c] = rem - p_gy[c] * p.g_W + (pix[c] - pp);            // a tail overshoot stays on the x axis (never used: pok)
+  }
+  const long y_ldb = p.y_ld * (long)sizeof(T);
+
+  auto issue = [&](int stage) {
+    unsigned char* At = smem + stage * STAGE_BYTES;
+    unsigned char* Bt = At + TILE_BYTES;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bool pok = pix[c] < P;
+      const unsigned aoff = (pok && a_cok) ? (unsigned)((long)pix[c] * y_ldb + a_col * (long)sizeof(T)) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_void_t)(At + (wid + 4 * c) * 1024), 16, aoff, 0, 0, 0);
+      unsigned boff = kOOB;
+      const int iy = p_gy[c] * p.mul_y + b_dy, ix = p_gx[c] * p.mul_x + b_dx;
+      if (pok && b_cok && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W)
+        boff = (unsigned)(((((long)p_img[c] * p.x_H + iy) * p.x_W + ix) * p.x_ld + b_ch) * (long)sizeof(T));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t)(Bt + (wid + 4 * c) * 1024), 16, boff, 0, 0, 0);
+      pix[c] += BK;
+      p_gx[c] += BK;
+      while (p_gx[c] >= p.g_W) {                                    // carry into rows / images
+        p_gx[c] -= p.g_W;
+        if (++p_gy[c] == p.g_H) { p_gy[c] = 0; ++p_img[c]; }
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](int stage) {
+    const unsigned char* At = smem + stage * STAGE_BYTES;
+    const unsigned char* Bt = At + TILE_BYTES;
+    if constexpr (sizeof(T) == 2) {
+      const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+      const int rowoff = 8 * (g >> 1) + q;                       // row & 3 == q
+      const int colch = 2 * (g & 1) + (pp >> 1), sub = (pp & 1) * 8;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int ch = ((wm * WTM + i * 32) >> 3) + colch;
+          const unsigned char* base = At + (ks * 16 + rowoff) * ROWB + ((ch ^ (q << 2)) << 4) + sub;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + 4 * ROWB));
+          const __attribute__((ext_vector_type(8))) short v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          af[i] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int ch = ((wn * WTN + j * 32) >> 3) + colch;
+          const unsigned char* base = Bt + (ks * 16 + rowoff) * ROWB + ((ch ^ (q << 2)) << 4) + sub;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + 4 * ROWB));
+          const __attribute__((ext_vector_type(8))) short v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bfr[j] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const float* Af = reinterpret_cast<const float*>(At);
+      const float* Bf = reinterpret_cast<const float*>(Bt);
+#pragma unroll
+      for (int t = 0; t < BK / 2; ++t) {
+        float af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = Af[(2 * t + h) * 128 + wm * WTM + i * 32 + r];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = Bf[(2 * t + h) * 128 + wn * WTN + j * 32 + r];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nk = kt_end - kt_begin;
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st)
+    if (st < nk) issue(st);
+  int it = 0;
+  const int steady = nk - (STAGES - 1);
+  for (; it < steady; ++it) {
+    wait_vmcnt<8>();                                               // 2 younger tiles x 4 DMAs stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue((it + STAGES - 1) % STAGES);
+    compute(it % STAGES);
+  }
+  for (; it < nk; ++it) {
+    wait_vmcnt_dyn(min(STAGES - 2, nk - 1 - it) * 4);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(it % STAGES);
+  }
+
+  // ---- epilogue: accumulators -> LDS fp32 [128][128] -> float4 rows of the slab [z][Cout][Ktot] ----------
+  __syncthreads();
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        ct[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BN + wn * WTN + j * 32 + r] = acc[i][j][e];
+  __syncthreads();
+  const int Cout = p.N;
+  float* __restrict__ slab = p.slab + (long)blockIdx.z * Cout * Ktot;
+  const bool vec = (Ktot % 4) == 0;
+  for (int c = tid; c < BM * (BN / 4); c += 256) {
+    const int ml = c / (BN / 4), nl = (c - ml * (BN / 4)) * 4;
+    const int m = m0 + ml, n = n0 + nl;
+    if (m >= Cout || n >= Ktot) continue;
+    const float4 v = *reinterpret_cast<const float4*>(ct + ml * BN + nl);
+    float* d = slab + (long)m * Ktot + n;
+    if (vec) stg_u4(d, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+    else { const float vv[4] = {v.x, v.y, v.z, v.w}; for (int q = 0; q < 4 && n + q < Ktot; ++q) d[q] = vv[q]; }
+  }
+}
+
 template <typename T>
 int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
   const int ncls = p.n_cls > 1 ? p.n_cls : 1;
@@ -665,7 +868,10 @@ int launch_wgrad(const mireg_conv_desc& p, hipStream_t stream) {
   const int Ktot = p.taps_y * p.taps_x * p.x_C;
   const int z = p.split_k > 1 ? p.split_k : 1;
   dim3 grid((unsigned)(((Cout + 127) / 128) * ((Ktot + 127) / 128)), 1, z);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, stream, p);
+  if (p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < (1L << 31) && p.w_bytes < (1L << 31))
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<T>), grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, stream, p);
   return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
 }
 

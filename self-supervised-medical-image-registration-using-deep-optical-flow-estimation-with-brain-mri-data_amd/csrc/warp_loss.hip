@@ -445,11 +445,12 @@ int mireg_stn_warp_fwd(const float* flow, long fsb, long fsc, long fsp, const fl
                    ((uintptr_t)flow % 16 == 0) && ((uintptr_t)warped % 16 == 0) && (!fixed || (uintptr_t)fixed % 16 == 0);
   const long npix = (long)B * h * w;
   if (vec) {
-    const int g = grid_for(npix / 4);
+    // kernels that end in 6 double atomics per block keep the grid at ~1 block per CU (contention on one line)
+    const int g = sums ? grid_for(npix / 4, 256) : grid_for(npix / 4);
     if (sums) hipLaunchKernelGGL((stn_warp_fwd_kernel<4, true>), dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame, fixed, warped, sums, B, C, h, w);
     else hipLaunchKernelGGL((stn_warp_fwd_kernel<4, false>), dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame, fixed, warped, sums, B, C, h, w);
   } else {
-    const int g = grid_for(npix);
+    const int g = sums ? grid_for(npix, 256) : grid_for(npix);
     if (sums) hipLaunchKernelGGL((stn_warp_fwd_kernel<1, true>), dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame, fixed, warped, sums, B, C, h, w);
     else hipLaunchKernelGGL((stn_warp_fwd_kernel<1, false>), dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame, fixed, warped, sums, B, C, h, w);
   }
@@ -468,7 +469,7 @@ int mireg_stn_warp_bwd(const float* flow, long fsb, long fsc, long fsp, const fl
 int mireg_loss_partials(const float* warped, const float* fixed, double* sums, long n, hipStream_t stream) {
   MIREG_CHECK_ARG(warped && fixed && sums && n > 0);
   MIREG_CHECK_ARG((uintptr_t)warped % 16 == 0 && (uintptr_t)fixed % 16 == 0);
-  hipLaunchKernelGGL(loss_partials_kernel, dim3(grid_for(n / 4 + 1)), dim3(kThreads), 0, stream, warped, fixed, sums, n);
+  hipLaunchKernelGGL(loss_partials_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(kThreads), 0, stream, warped, fixed, sums, n);
   MIREG_LAUNCH_RET();
 }
 
@@ -482,7 +483,7 @@ int mireg_loss_bwd(const float* warped, const float* fixed, const float* coef, f
 int mireg_smoothness_fwd(const float* flow, long fsb, long fsc, long fsp, double* sum, int B, int h, int w,
                          hipStream_t stream) {
   MIREG_CHECK_ARG(flow && sum && B > 0 && h > 0 && w > 0);
-  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(grid_for((long)B * h * w)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, sum, B, h, w);
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(grid_for((long)B * h * w, 256)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, sum, B, h, w);
   MIREG_LAUNCH_RET();
 }
 

@@ -356,7 +356,7 @@ class ConvLayer:
         bk = 32 if self.ws.code == DT_BF16 else 16
         tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
         nk = (dy.rows + bk - 1) // bk
-        self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((2 * NUM_CU + tiles - 1) // tiles, max(nk // 2, 1), 32))
+        self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU + tiles - 1) // tiles, max(nk // 8, 1), 192))
         self.wgrad_slab = torch.empty(self.wgrad_split, self.Co, self.Kf, device=self.ws.device, dtype=F32)
         if self.grad_w is None:
             self.grad_w = torch.zeros_like(self.weight, dtype=F32)
@@ -377,6 +377,7 @@ class ConvLayer:
         d.g_H, d.g_W, d.n_img = dy.H, dy.W, dy.B
         d.y, d.y_ld, d.N = dy.ptr, dy.ld, self.Co
         d.split_k, d.slab, d.dtype = self.wgrad_split, self.wgrad_slab.data_ptr(), self.ws.code
+        d.x_bytes, d.w_bytes = x.bytes_left, dy.bytes_left          # w_bytes carries the dy extent in WGRAD mode
         PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_kernel<128,128>",
                         2.0 * dy.rows * self.Co * self.kh * self.kw * self.Ci)
 
@@ -389,7 +390,7 @@ class ConvLayer:
 
 class BatchNormAct:
     """Train/eval BatchNorm2d + LeakyReLU on an NHWC view (reference FlowNetS/util.py:17-30)."""
-    MAX_BLOCKS = 1024
+    MAX_BLOCKS = 512
 
     def __init__(self, bn: torch.nn.BatchNorm2d, ws: Workspace, slope: float = 0.1):
         self.bn, self.ws, self.slope = bn, ws, slope
