@@ -186,6 +186,12 @@ int mireg_adam_step(const mireg_adam_job* jobs_dev, int njobs, int* step_dev, fl
 int mireg_correlation_fwd(const void* f1, long ld1, const void* f2, long ld2, void* out, long ldo, int B, int H,
                           int W, int C, int c_norm, int max_displacement, int stride2, float slope, int dtype,
                           hipStream_t stream);
+/* backward of the cost volume: g = d loss / d out with the LeakyReLU backward already applied (NHWC, D*D channels);
+ * df1 / df2 may be NULL; accumulate flags add into existing gradients (f1 usually has other consumers). */
+int mireg_correlation_bwd(const void* g, long ldg, const void* f1, long ld1, const void* f2, long ld2, void* df1,
+                          long ldd1, void* df2, long ldd2, int B, int H, int W, int C, int c_norm,
+                          int max_displacement, int stride2, int accumulate1, int accumulate2, int dtype,
+                          hipStream_t stream);
 /* ---- K10: PWCDCNet.warp, PWC/models/PWCNet.py:143-179 (flow fp32 [pix][ldf], pre-scaled by flow_scale) ---- */
 int mireg_pwc_warp_fwd(const void* x, long ldx, const float* flow, long ldf, float flow_scale, void* out, long ldo,
                        int B, int H, int W, int C, int dtype, hipStream_t stream);

@@ -115,6 +115,82 @@ correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__
   }
 }
 
+// Cost-volume backward.  With G = d loss / d corr (LeakyReLU backward already applied by the caller):
+//   WHICH 0: dF1[b,y,x,c]   = (1/C) sum_{dy,dx} G[b,y,x,(dy,dx)]               * F2[b, y+s2*dy, x+s2*dx, c]
+//   WHICH 1: dF2[b,y',x',c] = (1/C) sum_{dy,dx} G[b,y'-s2*dy,x'-s2*dx,(dy,dx)] * F1[b, y'-s2*dy, x'-s2*dx, c]
+// Per (b, row, dy) this is  Gband[32 x 32] . Frow[32 x C]  with Gband the banded matrix of displacement gradients,
+// run on the exact-fp32 MFMA (32x32x2, operands converted on load) so that bf16 storage needs no LDS transpose:
+// lane (r,h) feeds A[m=r][k=h] (a 2-byte/4-byte gather from G) and B[k=h][n=r] (32 consecutive channels).
+template <typename T, int WHICH>
+__global__ void __launch_bounds__(256)
+correlation_bwd_kernel(const T* __restrict__ g, long ldg, const T* __restrict__ fo, long ldo_, T* __restrict__ dout, long ldd,
+                       int B, int H, int W, int C, int c_norm, int R, int s2, int accumulate) {
+  constexpr int NT = 8;                                        // up to 256 channels per pass
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int D = 2 * R + 1;
+  const int xt = (W + 31) / 32;
+  const long units = (long)B * H * xt;
+  const float inv_c = 1.f / (float)c_norm;
+  for (long u = (long)blockIdx.x * 4 + wid; u < units; u += (long)gridDim.x * 4) {
+    const int x0 = (int)(u % xt) * 32;
+    const int y = (int)((u / xt) % H);
+    const int b = (int)(u / ((long)xt * H));
+    const int xm = x0 + r;                                     // the pixel of accumulator row r
+    for (int c0 = 0; c0 < C; c0 += 32 * NT) {
+      const int nt = min(NT, (C - c0 + 31) / 32);
+      f32x16 acc[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+      for (int dyi = 0; dyi < D; ++dyi) {
+        const int yy = WHICH == 0 ? y + (dyi - R) * s2 : y - (dyi - R) * s2;     // row of the other feature map
+        if (yy < 0 || yy >= H) continue;
+        const int gy = WHICH == 0 ? y : yy;                    // row of G
+        const int k_lo = max(0, x0 - R * s2), k_hi = min(W - 1, x0 + 31 + R * s2);
+        for (int k0 = k_lo & ~1; k0 <= k_hi; k0 += 2) {
+          const int k = k0 + h;                                // this lane's K index = pixel of the other map
+          float a = 0.f;
+          if (xm < W && k >= 0 && k < W) {
+            const int diff = WHICH == 0 ? k - xm : xm - k;     // s2 * dx
+            const int gx = WHICH == 0 ? xm : k;                // pixel of G
+            if (diff % s2 == 0) {
+              const int dxi = diff / s2 + R;
+              if (dxi >= 0 && dxi < D) a = ldf(g + (((long)b * H + gy) * W + gx) * ldg + dyi * D + dxi);
+            }
+          }
+          const T* frow = fo + (((long)b * H + yy) * W + min(max(k, 0), W - 1)) * ldo_ + c0;
+          const bool kok = k >= 0 && k < W;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if (j < nt) {
+              const int c = j * 32 + r;
+              const float bv = (kok && c0 + c < C) ? ldf(frow + c) : 0.f;
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (j >= nt) continue;
+        const int c = c0 + j * 32 + r;
+        if (c >= C) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int xo = x0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (xo >= W) continue;
+          T* d = dout + (((long)b * H + y) * W + xo) * ldd + c;
+          float v = acc[j][e] * inv_c;
+          if (accumulate) v += ldf(d);
+          stf(d, v);
+        }
+      }
+    }
+  }
+}
+
 // PWCDCNet.warp (PWC/models/PWCNet.py:143-179): grid normalised with (W-1) but sampled with align_corners=False,
 // so the tap coordinate is ((2(x+u)/(W-1) - 1 + 1) * W - 1) / 2; output * (bilinear(ones) >= 0.9999).
 template <typename T>
@@ -197,6 +273,25 @@ int mireg_correlation_fwd(const void* f1, long ld1, const void* f2, long ld2, vo
   else if (dtype == MIREG_DTYPE_F32)
     hipLaunchKernelGGL((correlation_fwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)f1, ld1, (const float*)f2, ld2, (float*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
   else return MIREG_ERR_ARG;
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_correlation_bwd(const void* g, long ldg, const void* f1, long ld1, const void* f2, long ld2, void* df1, long ldd1,
+                          void* df2, long ldd2, int B, int H, int W, int C, int c_norm, int max_displacement, int stride2,
+                          int accumulate1, int accumulate2, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(g && f1 && f2 && (df1 || df2) && B > 0 && H > 0 && W > 0 && C > 0 && c_norm > 0 && stride2 > 0);
+  MIREG_CHECK_ARG(max_displacement % stride2 == 0 && max_displacement / stride2 <= 15);
+  const long units = (long)B * H * ((W + 31) / 32);
+  long gr = (units + 3) / 4;
+  if (gr > 4096) gr = 4096;
+  const int R = max_displacement / stride2;
+  if (dtype == MIREG_DTYPE_BF16) {
+    if (df1) hipLaunchKernelGGL((correlation_bwd_kernel<__bf16, 0>), dim3((unsigned)gr), dim3(256), 0, stream, (const __bf16*)g, ldg, (const __bf16*)f2, ld2, (__bf16*)df1, ldd1, B, H, W, C, c_norm, R, stride2, accumulate1);
+    if (df2) hipLaunchKernelGGL((correlation_bwd_kernel<__bf16, 1>), dim3((unsigned)gr), dim3(256), 0, stream, (const __bf16*)g, ldg, (const __bf16*)f1, ld1, (__bf16*)df2, ldd2, B, H, W, C, c_norm, R, stride2, accumulate2);
+  } else if (dtype == MIREG_DTYPE_F32) {
+    if (df1) hipLaunchKernelGGL((correlation_bwd_kernel<float, 0>), dim3((unsigned)gr), dim3(256), 0, stream, (const float*)g, ldg, (const float*)f2, ld2, (float*)df1, ldd1, B, H, W, C, c_norm, R, stride2, accumulate1);
+    if (df2) hipLaunchKernelGGL((correlation_bwd_kernel<float, 1>), dim3((unsigned)gr), dim3(256), 0, stream, (const float*)g, ldg, (const float*)f1, ld1, (float*)df2, ldd2, B, H, W, C, c_norm, R, stride2, accumulate2);
+  } else return MIREG_ERR_ARG;
   MIREG_LAUNCH_RET();
 }
 

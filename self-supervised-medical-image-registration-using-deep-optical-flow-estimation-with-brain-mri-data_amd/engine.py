@@ -233,6 +233,7 @@ class ConvLayer:
                 self.classes.append(dict(py=py, px=px, ky0=ky0, kx0=kx0, nty=nty, ntx=ntx, cy=cy, cx=cx, K=K, pack=pack))
         self.wgrad_slab: Optional[torch.Tensor] = None
         self.wgrad_split = 1
+        self.n_slots = 1
         self.grad_w: Optional[torch.Tensor] = None
         self.grad_b: Optional[torch.Tensor] = None
 
@@ -254,7 +255,7 @@ class ConvLayer:
         j.src, j.dst = self.wgrad_slab.data_ptr(), self.grad_w.data_ptr()
         j.Co, j.Ci, j.kh, j.kw = self.Co, self.Ci, self.kh, self.kw
         j.Cpad, j.Cop, j.ld, j.stride, j.nclass = self.Cip, self.Cop, self.Kf, self.s, 0
-        j.nsplit, j.accumulate = self.wgrad_split, int(accumulate)
+        j.nsplit, j.accumulate = self.wgrad_split * self.n_slots, int(accumulate)
         return j
 
     # ---- launches -----------------------------------------------------------------------------
@@ -357,14 +358,15 @@ class ConvLayer:
         tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
         nk = (dy.rows + bk - 1) // bk
         self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU + tiles - 1) // tiles, max(nk // 8, 1), 192))
-        self.wgrad_slab = torch.empty(self.wgrad_split, self.Co, self.Kf, device=self.ws.device, dtype=F32)
+        self.wgrad_slab = torch.zeros(self.n_slots * self.wgrad_split, self.Co, self.Kf, device=self.ws.device, dtype=F32)
         if self.grad_w is None:
             self.grad_w = torch.zeros_like(self.weight, dtype=F32)
         if self.bias is not None and self.grad_b is None:
             self.grad_b = torch.zeros_like(self.bias, dtype=F32)
 
-    def run_wgrad(self, x: View, dy: View) -> None:
-        """x: tensor in this conv's INPUT space (C = Ci), dy: tensor in its OUTPUT space (C = Co)."""
+    def run_wgrad(self, x: View, dy: View, slot: int = 0) -> None:
+        """x: tensor in this conv's INPUT space (C = Ci), dy: tensor in its OUTPUT space (C = Co).
+        slot selects the slab group of a weight-shared layer (the unpack sums all groups)."""
         if self.wgrad_slab is None:
             self.plan_wgrad(x, dy)
         assert x.C <= self.Cip and x.c0 + self.Cip <= x.ld and dy.c0 + rup(self.Co, 8) <= dy.ld, self.name
@@ -376,7 +378,8 @@ class ConvLayer:
         d.step_y = d.step_x = self.d
         d.g_H, d.g_W, d.n_img = dy.H, dy.W, dy.B
         d.y, d.y_ld, d.N = dy.ptr, dy.ld, self.Co
-        d.split_k, d.slab, d.dtype = self.wgrad_split, self.wgrad_slab.data_ptr(), self.ws.code
+        d.split_k, d.dtype = self.wgrad_split, self.ws.code
+        d.slab = self.wgrad_slab[slot * self.wgrad_split].data_ptr()
         d.x_bytes, d.w_bytes = x.bytes_left, dy.bytes_left          # w_bytes carries the dy extent in WGRAD mode
         PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_kernel<128,128>",
                         2.0 * dy.rows * self.Co * self.kh * self.kw * self.Ci)
@@ -409,9 +412,10 @@ class BatchNormAct:
                   bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(mom), float(bn.eps),
                   int(training), self.slope, self.partial.data_ptr(), self.ss.data_ptr(), self.ws.code, _stream())
 
-    def backward(self, y: View, da: View, dy: View) -> None:
+    def backward(self, y: View, da: View, dy: View, acc_param_grads: bool = False) -> None:
         _lib.call("mireg_bn_backward", y.ptr, y.ld, da.ptr, da.ld, dy.ptr, dy.ld, self.ss.data_ptr(),
-                  self.partial.data_ptr(), self.red.data_ptr(), self.grad_g.data_ptr(), self.grad_b.data_ptr(), 0, y.rows,
+                  self.partial.data_ptr(), self.red.data_ptr(), self.grad_g.data_ptr(), self.grad_b.data_ptr(),
+                  int(acc_param_grads), y.rows,
                   self.C, self.slope, self.ws.code, _stream())
 
 

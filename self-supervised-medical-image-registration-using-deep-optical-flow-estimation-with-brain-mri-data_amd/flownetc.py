@@ -5,8 +5,8 @@ eval -> (flow2,).  The siamese conv1-3 run once per stream (BatchNorm batch stat
 as the reference's two self.conv1(...) calls), the 441-channel cost volume comes from the MFMA correlation
 kernel with its LeakyReLU fused, conv_redir and the cost volume are written straight into the 473-channel
 input buffer of conv3_1 (no torch.cat), and the refinement decoder is shared with FlowNetS.
-Forward (train + eval mode) is implemented; the backward needs the correlation backward kernels and raises
-until they land.
+Backward: decoder shared with FlowNetS, cost-volume backward on the exact-fp32 MFMA (csrc/correlation.hip), the two
+siamese streams accumulate into one weight gradient (one wgrad slab group per stream).
 """
 from __future__ import annotations
 
@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import _lib
 from .correlation import Correlation, correlation_views
-from .engine import BatchNormAct, F32, nchw_to_view
+from .engine import BatchNormAct, F32, _stream, lrelu_bwd, nchw_to_view
 from .flownets import DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block
 
 
@@ -34,12 +34,14 @@ class FlowNetCEngine(PredictorEngineBase, FlowNetDecoderMixin):
                [(n, k, s) for n, _, _, k, s in ENCODER[4:]]
         for name, k, s in spec:
             seq = getattr(m, name)
-            self.add_conv(name, seq[0], s, (k - 1) // 2)
+            self.add_conv(name, seq[0], s, (k - 1) // 2, uses=2 if name in ("conv1", "conv2", "conv3") else 1)
         # siamese layers keep one BatchNormAct per stream (separate batch statistics / saved scale-shift)
         for name in ("conv1", "conv2", "conv3"):
             if self.bn:
                 self.bns[name + "@a"] = BatchNormAct(getattr(m, name)[1], ws, SLOPE)
                 self.bns[name + "@b"] = BatchNormAct(getattr(m, name)[1], ws, SLOPE)
+                self.bns[name + "@b"].grad_g = self.bns[name + "@a"].grad_g       # one gradient per shared parameter
+                self.bns[name + "@b"].grad_b = self.bns[name + "@a"].grad_b
         for name, _, _ in spec[3:]:
             if self.bn:
                 self.bns[name] = BatchNormAct(getattr(m, name)[1], ws, SLOPE)
@@ -54,16 +56,18 @@ class FlowNetCEngine(PredictorEngineBase, FlowNetDecoderMixin):
         self.in31 = new(B, *hs[3], 473)                  # [conv_redir 32 | corr 441]
         self.a4, self.a5 = new(B, *hs[4], 512), new(B, *hs[5], 512)
         self.a6, self.a61 = new(B, *hs[6], 1024), new(B, *hs[6], 1024)
-        shapes = {"conv1": (1, 64), "conv2": (2, 128), "conv3": (3, 256), "conv_redir": (3, 32), "conv3_1": (3, 256),
-                  "conv4": (4, 512), "conv4_1": (4, 512), "conv5": (5, 512), "conv5_1": (5, 512), "conv6": (6, 1024),
-                  "conv6_1": (6, 1024)}
+        shapes = {"conv1@a": (1, 64), "conv2@a": (2, 128), "conv3@a": (3, 256), "conv1@b": (1, 64), "conv2@b": (2, 128),
+                  "conv3@b": (3, 256), "conv_redir": (3, 32), "conv3_1": (3, 256), "conv4": (4, 512), "conv4_1": (4, 512),
+                  "conv5": (5, 512), "conv5_1": (5, 512), "conv6": (6, 1024), "conv6_1": (6, 1024)}
         self.raw = {n: new(B, *hs[l], c) for n, (l, c) in shapes.items()} if self.bn else {}
+        self.grads_ready = False
 
     def _block(self, name: str, src, dst, training: bool, bn_key: str = None) -> None:
         lay = self.layers[name]
+        key = bn_key or name
         if self.bn:
-            lay.run_fwd_form(src, self.raw[name])
-            self.bns[bn_key or name].forward(self.raw[name], dst, training)
+            lay.run_fwd_form(src, self.raw[key])
+            self.bns[key].forward(self.raw[key], dst, training)
         else:
             lay.run_fwd_form(src, dst, slope=SLOPE)
 
@@ -98,21 +102,66 @@ class FlowNetCEngine(PredictorEngineBase, FlowNetDecoderMixin):
             flows += [self.flow32[l].nchw() for l in (3, 4, 5, 6)]
         return flows
 
+    def _ensure_grad_buffers(self) -> None:
+        if self.grads_ready:
+            return
+        new, hs, B = self.ws.new, self.hs, self.B
+        self.setup_decoder_grads()
+        self.da4, self.da5, self.da6 = new(B, *hs[4], 512), new(B, *hs[5], 512), new(B, *hs[6], 1024)
+        self.din31 = new(B, *hs[3], 473)
+        self.dc3 = {s: new(B, *hs[3], 256) for s in "ab"}
+        self.dc2b = new(B, *hs[2], 128)
+        self.dc1 = {s: new(B, *hs[1], 64) for s in "ab"}
+        self.draw = {n: new(B, v.H, v.W, v.C) for n, v in self.raw.items()}
+        self.grads_ready = True
+
     def backward(self, gflows) -> None:
-        raise NotImplementedError("FlowNetC backward (correlation backward kernels) is not implemented yet; "
-                                  "see DESIGN.md section 9")
+        """gflows: gradients wrt (flow2, flow3, flow4, flow5, flow6) as (B,2,h,w) fp32 or None."""
+        self._ensure_grad_buffers()
+        c, dc = self.cat, self.dcat
+        g = list(gflows) + [None] * (5 - len(gflows))
+        self.decoder_backward({2: g[0], 3: g[1], 4: g[2], 5: g[3], 6: g[4]}, None)
+        cb = self.chain_backward
+        cb("conv6_1", self.a6, self.a61, self.da6, False, self.da61)
+        cb("conv6", c[5].slice(0, 512), self.a6, dc[5].slice(0, 512), True, self.da6)
+        cb("conv5_1", self.a5, c[5].slice(0, 512), self.da5, False, dc[5].slice(0, 512))
+        cb("conv5", c[4].slice(0, 512), self.a5, dc[4].slice(0, 512), True, self.da5)
+        cb("conv4_1", self.a4, c[4].slice(0, 512), self.da4, False, dc[4].slice(0, 512))
+        cb("conv4", c[3].slice(0, 256), self.a4, dc[3].slice(0, 256), True, self.da4)
+        cb("conv3_1", self.in31, c[3].slice(0, 256), self.din31, False, dc[3].slice(0, 256))
+        # din31 = [d conv_redir out (32) | d corr out (441)]
+        cb("conv_redir", self.c3["a"], self.in31.slice(0, 32), self.dc3["a"], False, self.din31.slice(0, 32))
+        gcorr = self.din31.slice(32, 441)
+        lrelu_bwd(gcorr, self.in31.slice(32, 441), SLOPE, self.ws)
+        fa, fb = self.c3["a"], self.c3["b"]
+        _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, fa.ptr, fa.ld, fb.ptr, fb.ld, self.dc3["a"].ptr,
+                  self.dc3["a"].ld, self.dc3["b"].ptr, self.dc3["b"].ld, self.B, fa.H, fa.W, 256, 256, 20, 2, 1, 0,
+                  self.ws.code, _stream())
+        # siamese streams: same weights, wgrad slot per stream, shared BatchNorm parameter gradients accumulate
+        cb("conv3", c[2].slice(0, 128), fa, dc[2].slice(0, 128), True, self.dc3["a"], "conv3@a", "conv3@a", 0, False)
+        cb("conv2", self.c1["a"], c[2].slice(0, 128), self.dc1["a"], False, dc[2].slice(0, 128), "conv2@a", "conv2@a", 0, False)
+        cb("conv1", self.xa, self.c1["a"], None, False, self.dc1["a"], "conv1@a", "conv1@a", 0, False)
+        cb("conv3", self.c2b, fb, self.dc2b, False, self.dc3["b"], "conv3@b", "conv3@b", 1, True)
+        cb("conv2", self.c1["b"], self.c2b, self.dc1["b"], False, self.dc2b, "conv2@b", "conv2@b", 1, True)
+        cb("conv1", self.xb, self.c1["b"], None, False, self.dc1["b"], "conv1@b", "conv1@b", 1, True)
+        self.join_side()
+        self.unpack_grads()
 
 
 class _FlowNetCFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, *params):
         eng = module.engine_for(x)
-        ctx.eng = eng
+        ctx.eng, ctx.module = eng, module
         return tuple(eng.forward(x, module.training))
 
     @staticmethod
     def backward(ctx, *g):
-        ctx.eng.backward(g)
+        eng = ctx.eng
+        eng.backward(g if eng.training_cache else (g[0], None, None, None, None))
+        table = eng.param_grads()
+        grads = tuple(table[id(p)].clone() if id(p) in table else None for p in ctx.module.parameters())
+        return (None, None) + grads
 
 
 class FlowNetC(nn.Module):

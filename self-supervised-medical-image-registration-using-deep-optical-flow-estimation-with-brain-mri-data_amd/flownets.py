@@ -46,8 +46,9 @@ class PredictorEngineBase:
         self.training_cache = False
 
     # -- parameters ---------------------------------------------------------------------------------
-    def add_conv(self, name: str, conv: nn.Module, stride: int, pad: int, dil: int = 1) -> ConvLayer:
+    def add_conv(self, name: str, conv: nn.Module, stride: int, pad: int, dil: int = 1, uses: int = 1) -> ConvLayer:
         lay = ConvLayer(name, conv.weight, conv.bias, stride, pad, dil, self.ws)
+        lay.n_slots = uses                    # weight-shared layers (siamese streams) get one wgrad slab per use
         self.layers[name] = lay
         return lay
 
@@ -56,9 +57,9 @@ class PredictorEngineBase:
     # forked onto a second HIP stream (captured as a parallel hipGraph branch) and joined before the unpack.
     use_side_stream = True
 
-    def wgrad_async(self, lay: ConvLayer, x: View, dy: View) -> None:
+    def wgrad_async(self, lay: ConvLayer, x: View, dy: View, slot: int = 0) -> None:
         if not self.use_side_stream:
-            lay.run_wgrad(x, dy)
+            lay.run_wgrad(x, dy, slot)
             return
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.ws.device)
@@ -66,7 +67,7 @@ class PredictorEngineBase:
         ev.record(torch.cuda.current_stream())
         self._side.wait_event(ev)
         with torch.cuda.stream(self._side):
-            lay.run_wgrad(x, dy)
+            lay.run_wgrad(x, dy, slot)
 
     def join_side(self) -> None:
         if getattr(self, "_side", None) is not None:
@@ -149,6 +150,82 @@ class FlowNetDecoderMixin:
             feat = c[lvl]
             L[f"predict_flow{lvl}"].run_fwd_form(feat, self.flowT[lvl], y32=self.flow32[lvl])
 
+    def setup_decoder_grads(self) -> None:
+        new, hs, B = self.ws.new, self.hs, self.B
+        self.dcat = {lvl: new(B, *hs[lvl], v.C) for lvl, v in self.cat.items()}
+        self.da61 = new(B, *hs[6], 1024)
+        self.dflowT = {lvl: new(B, *hs[lvl], 2) for lvl in PREDICT}
+        self.dflow32 = new(B, *hs[2], 2, dtype=F32, pad=2)
+
+    def decoder_backward(self, glvl: Dict[int, Optional[torch.Tensor]], g0: Optional[torch.Tensor]) -> None:
+        """glvl[l]: loss gradient of flow l (B,2,h,w fp32 or None); g0: gradient of the 256x256 upsampled flow2
+        (FlowNetS only).  Leaves every decoder-side contribution in dcat[2..5] and da61."""
+        L, c, dc, B, st = self.layers, self.cat, self.dcat, self.B, _stream()
+
+        def load_loss_grad(lvl: int) -> None:
+            gt = glvl.get(lvl)
+            dst = self.dflowT[lvl]
+            if lvl == 2 and g0 is not None:
+                d32 = self.dflow32
+                if gt is None:
+                    d32.buf.zero_()
+                else:
+                    nchw_to_view(gt.contiguous(), 0, 2, d32)
+                g0c = g0.contiguous()
+                _lib.call("mireg_resize_bilinear_bwd", g0c.data_ptr(), d32.ptr, B, 2, d32.H, d32.W, 256, 256,
+                          d32.H * d32.W * 2, 1, 2, 2 * 256 * 256, 256 * 256, 1, 0, 1.0, st)
+                cast_from_f32(dst, d32)
+            elif gt is None:
+                dst.buf.zero_()
+            else:
+                nchw_to_view(gt.contiguous(), 0, 2, dst)
+
+        load_loss_grad(2)
+        pf = L["predict_flow2"]
+        self.wgrad_async(pf, c[2], self.dflowT[2])
+        pf.run_bias_grad(self.dflowT[2])
+        pf.run_dgrad_form(self.dflowT[2], dc[2])                              # dcat2 <- (beta 0)
+        for lvl in (2, 3, 4, 5):
+            # dcat[lvl] holds every decoder-side contribution now; push it one level coarser
+            cs, cd = self.skip_c[lvl], DECONV[lvl][1]
+            feat_prev, dfeat_prev = (c[lvl + 1], dc[lvl + 1]) if lvl < 5 else (self.a61, self.da61)
+            # flow upsampler (lvl+1 -> lvl): no activation
+            gup = dc[lvl].slice(cs + cd, 2)
+            up = L[f"up{lvl + 1}"]
+            load_loss_grad(lvl + 1)                                           # dflowT[lvl+1] <- loss grad
+            self.wgrad_async(up, gup, self.flowT[lvl + 1])
+            up.run_bias_grad(gup)
+            up.run_fwd_form(gup, self.dflowT[lvl + 1], bias=False, accumulate=True)
+            # feature deconv (lvl+1 -> lvl) + LeakyReLU
+            gde = dc[lvl].slice(cs, cd)
+            lrelu_bwd(gde, c[lvl].slice(cs, cd), SLOPE, self.ws)
+            de = L[f"deconv{lvl}"]
+            self.wgrad_async(de, gde, feat_prev)
+            de.run_bias_grad(gde)
+            # predict_flow{lvl+1} writes dfeat_prev first (beta 0), the deconv then accumulates into it
+            pfn = L[f"predict_flow{lvl + 1}"]
+            self.wgrad_async(pfn, feat_prev, self.dflowT[lvl + 1])
+            pfn.run_bias_grad(self.dflowT[lvl + 1])
+            pfn.run_dgrad_form(self.dflowT[lvl + 1], dfeat_prev)
+            de.run_fwd_form(gde, dfeat_prev, bias=False, accumulate=True)
+
+    def chain_backward(self, name: str, src: View, dst: View, dsrc: Optional[View], acc: bool, ddst: View,
+                       bn_key: Optional[str] = None, raw_key: Optional[str] = None, slot: int = 0,
+                       acc_bn: bool = False) -> None:
+        """Backward of one conv(+BN)+LeakyReLU block: ddst = grad wrt its activated output, dsrc = grad wrt its input."""
+        lay = self.layers[name]
+        if self.bn:
+            rk = raw_key or name
+            self.bns[bn_key or name].backward(self.raw[rk], ddst, self.draw[rk], acc_bn)
+            dy = self.draw[rk]
+        else:
+            lrelu_bwd(ddst, dst, SLOPE, self.ws)
+            dy = ddst
+            lay.run_bias_grad(dy, accumulate=slot > 0)
+        self.wgrad_async(lay, src, dy, slot)
+        if dsrc is not None:
+            lay.run_dgrad_form(dy, dsrc, accumulate=acc)
+
 
 class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
     def __init__(self, module: "FlowNetS", B: int, H: int, W: int, device, dtype: torch.dtype):
@@ -213,15 +290,12 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
     def _ensure_grad_buffers(self) -> None:
         if self.grads_ready:
             return
-        ws, new, hs, B = self.ws, self.ws.new, self.hs, self.B
-        self.dcat = {lvl: new(B, *hs[lvl], v.C) for lvl, v in self.cat.items()}
+        new, hs, B = self.ws.new, self.hs, self.B
+        self.setup_decoder_grads()
         self.da1, self.da3, self.da4 = new(B, *hs[1], 64), new(B, *hs[3], 256), new(B, *hs[4], 512)
-        self.da5, self.da6, self.da61 = new(B, *hs[5], 512), new(B, *hs[6], 1024), new(B, *hs[6], 1024)
+        self.da5, self.da6 = new(B, *hs[5], 512), new(B, *hs[6], 1024)
         self.draw = {n: new(B, v.H, v.W, v.C) for n, v in self.raw.items()}
-        self.dflowT = {lvl: new(B, *hs[lvl], 2) for lvl in PREDICT}
-        self.dflow32 = new(B, *hs[2], 2, dtype=F32, pad=2)
-        self.gtmp = {lvl: torch.zeros(B, 2, *hs[lvl], device=ws.device, dtype=F32) for lvl in PREDICT}
-        c, dc = self.cat, self.dcat
+        dc = self.dcat
         self.enc_dio = {  # (grad wrt conv input, accumulate?), grad wrt conv output (activated)
             "conv1": (None, False, self.da1), "conv2": (self.da1, False, dc[2].slice(0, 128)),
             "conv3": (dc[2].slice(0, 128), True, self.da3), "conv3_1": (self.da3, False, dc[3].slice(0, 256)),
@@ -233,74 +307,12 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
     def backward(self, gflows: Sequence[Optional[torch.Tensor]]) -> None:
         """gflows: gradients wrt (flow0, flow2, flow3, flow4, flow5, flow6) as (B,2,h,w) fp32 or None."""
         self._ensure_grad_buffers()
-        L, c, dc, B, st = self.layers, self.cat, self.dcat, self.B, _stream()
         g = list(gflows) + [None] * (6 - len(gflows))
-        glvl = {2: g[1], 3: g[2], 4: g[3], 5: g[4], 6: g[5]}
-
-        def load_loss_grad(lvl: int) -> None:
-            """dflowT[lvl] <- loss gradient (zero if the flow was unused)."""
-            gt = glvl[lvl]
-            dst = self.dflowT[lvl]
-            if lvl == 2:
-                d32 = self.dflow32
-                if gt is None:
-                    d32.buf.zero_()
-                else:
-                    nchw_to_view(gt.contiguous(), 0, 2, d32)
-                if g[0] is not None:
-                    g0 = g[0].contiguous()
-                    _lib.call("mireg_resize_bilinear_bwd", g0.data_ptr(), d32.ptr, B, 2, d32.H, d32.W, 256, 256,
-                              d32.H * d32.W * 2, 1, 2, 2 * 256 * 256, 256 * 256, 1, 0, 1.0, st)
-                cast_from_f32(dst, d32)
-            elif gt is None:
-                dst.buf.zero_()
-            else:
-                nchw_to_view(gt.contiguous(), 0, 2, dst)
-
-        # ---- decoder, fine -> coarse ---------------------------------------------------------------
-        load_loss_grad(2)
-        pf = L["predict_flow2"]
-        self.wgrad_async(pf, c[2], self.dflowT[2])
-        pf.run_bias_grad(self.dflowT[2])
-        pf.run_dgrad_form(self.dflowT[2], dc[2])                              # dcat2 <- (beta 0)
-        for lvl in (2, 3, 4, 5):
-            # dcat[lvl] holds every decoder-side contribution now; push it one level coarser
-            cs, cd = self.skip_c[lvl], DECONV[lvl][1]
-            feat_prev, dfeat_prev = (c[lvl + 1], dc[lvl + 1]) if lvl < 5 else (self.a61, self.da61)
-            # flow upsampler (lvl+1 -> lvl): no activation
-            gup = dc[lvl].slice(cs + cd, 2)
-            up = L[f"up{lvl + 1}"]
-            load_loss_grad(lvl + 1)                                           # dflowT[lvl+1] <- loss grad
-            self.wgrad_async(up, gup, self.flowT[lvl + 1])
-            up.run_bias_grad(gup)
-            up.run_fwd_form(gup, self.dflowT[lvl + 1], bias=False, accumulate=True)
-            # feature deconv (lvl+1 -> lvl) + LeakyReLU
-            gde = dc[lvl].slice(cs, cd)
-            lrelu_bwd(gde, c[lvl].slice(cs, cd), SLOPE, self.ws)
-            de = L[f"deconv{lvl}"]
-            self.wgrad_async(de, gde, feat_prev)
-            de.run_bias_grad(gde)
-            # predict_flow{lvl+1} writes dfeat_prev first (beta 0), the deconv then accumulates into it
-            pfn = L[f"predict_flow{lvl + 1}"]
-            self.wgrad_async(pfn, feat_prev, self.dflowT[lvl + 1])
-            pfn.run_bias_grad(self.dflowT[lvl + 1])
-            pfn.run_dgrad_form(self.dflowT[lvl + 1], dfeat_prev)
-            de.run_fwd_form(gde, dfeat_prev, bias=False, accumulate=True)
-        # ---- encoder, coarse -> fine ---------------------------------------------------------------
-        for name, *_ in reversed(ENCODER):
+        self.decoder_backward({2: g[1], 3: g[2], 4: g[3], 5: g[4], 6: g[5]}, g[0])
+        for name, *_ in reversed(ENCODER):                                    # encoder, coarse -> fine
             src, dst = self.enc_io[name]
             dsrc, acc, ddst = self.enc_dio[name]
-            lay = L[name]
-            if self.bn:
-                self.bns[name].backward(self.raw[name], ddst, self.draw[name])
-                dy = self.draw[name]
-            else:
-                lrelu_bwd(ddst, dst, SLOPE, self.ws)
-                dy = ddst
-                lay.run_bias_grad(dy)
-            self.wgrad_async(lay, src, dy)
-            if dsrc is not None:
-                lay.run_dgrad_form(dy, dsrc, accumulate=acc)
+            self.chain_backward(name, src, dst, dsrc, acc, ddst)
         self.join_side()
         self.unpack_grads()
 

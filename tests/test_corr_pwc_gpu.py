@@ -112,3 +112,56 @@ def test_pwc_bf16_close_and_registration_wrapper():
     assert len(f32) == 7 and len(w32) == 7
     for a, b in zip(f32[:3], f16[:3]):
         assert ((a - b).double().norm() / a.double().norm().clamp_min(1e-9)).item() < 8e-2
+
+
+def test_correlation_backward_vs_autograd():
+    """dF1 / dF2 of the cost volume against torch autograd through the oracle's definition (fp32 + bf16 storage)."""
+    from mireg import _lib
+    from mireg.engine import Workspace, _stream
+    for prec, tol in (("fp32", 3e-5), ("bf16", 2e-2)):
+        dt = torch.float32 if prec == "fp32" else torch.bfloat16
+        ws = Workspace(torch.device(DEV), dt)
+        for (md, s2, C, H, W, B) in ((20, 2, 256, 32, 32, 1), (4, 1, 96, 16, 40, 2), (4, 1, 200, 4, 4, 2)):
+            f1 = (nets.analytic_input((B, C, H, W), seed=1) - 0.5)
+            f2 = (nets.analytic_input((B, C, H, W), seed=2) - 0.5)
+            D = 2 * (md // s2) + 1
+            g = nets.analytic_input((B, D * D, H, W), seed=3) - 0.5
+            if prec == "bf16":
+                f1, f2, g = f1.bfloat16().float(), f2.bfloat16().float(), g.bfloat16().float()
+            a, b = f1.clone().requires_grad_(), f2.clone().requires_grad_()
+            (oops.correlation(a, b, md, 1, md, 1, s2, 1) * g).sum().backward()
+            v1, v2, vg = ws.new(B, H, W, C), ws.new(B, H, W, C), ws.new(B, H, W, D * D)
+            v1.buf[..., :C] = f1.permute(0, 2, 3, 1).to(DEV); v2.buf[..., :C] = f2.permute(0, 2, 3, 1).to(DEV)
+            vg.buf[..., :D * D] = g.permute(0, 2, 3, 1).to(DEV)
+            d1, d2 = ws.new(B, H, W, C), ws.new(B, H, W, C)
+            _lib.call("mireg_correlation_bwd", vg.ptr, vg.ld, v1.ptr, v1.ld, v2.ptr, v2.ld, d1.ptr, d1.ld, d2.ptr, d2.ld,
+                      B, H, W, C, C, md, s2, 0, 0, ws.code, _stream())
+            assert _rel(d1.nchw().float(), a.grad) < tol, (prec, md, "dF1")
+            assert _rel(d2.nchw().float(), b.grad) < tol, (prec, md, "dF2")
+
+
+def test_flownetc_training_step_matches_oracle():
+    """FlowNetC fp32: gradients through decoder, cost volume and both siamese streams vs the CPU oracle autograd."""
+    import mireg
+    torch.manual_seed(0)
+    m = mireg.FlowNetC(None, batchNorm=True, precision="fp32")
+    nets.analytic_weights_(m)
+    o = nets.FlowNetC(None, batchNorm=True)
+    o.load_state_dict(m.state_dict(), strict=False)
+    m = m.to(DEV).train(); o.train()
+    x = nets.analytic_input((4, 2, 128, 128), seed=9)
+
+    def objective(fl, dev):
+        return sum((f * torch.cos(torch.arange(f.numel(), dtype=torch.float32).reshape(f.shape) * 0.01).to(dev)).sum() for f in fl)
+    objective(o(x), "cpu").backward()
+    objective(m(x.to(DEV)), DEV).backward()
+    P, Q = dict(m.named_parameters()), dict(o.named_parameters())
+    worst = 0.0
+    for k in ("conv1.0.weight", "conv1.1.weight", "conv2.0.weight", "conv3.0.weight", "conv3.1.bias", "conv_redir.0.weight",
+              "conv3_1.0.weight", "conv4.0.weight", "conv6_1.0.weight", "deconv5.0.weight", "deconv5.0.bias",
+              "predict_flow4.weight", "predict_flow4.bias", "upsampled_flow4_to_3.weight", "upsampled_flow4_to_3.bias"):
+        a, b = P[k].grad.detach().cpu().double(), Q[k].grad.double()
+        rel = ((a - b).norm() / b.norm()).item()
+        worst = max(worst, rel)
+        assert rel < 2e-2, (k, rel)
+    print("worst relative L2 gradient error", worst)
