@@ -169,13 +169,17 @@ def main():
             nb = 4
             xe, se = make_pairs(nb, args.size, seed=8, magnitude=(0.5, 1.0))
             ev = trainer.evaluate(xe.to(dev), se.to(dev))
+            if "dice" not in ev:
+                raise RuntimeError("top flow is not at image resolution: Dice undefined for this predictor")
             om = onets.OpticalFlowReg(args.model)
-            om.load_state_dict(model.state_dict())
+            om.load_state_dict(model.state_dict(), strict=False)
             om.eval()
             with torch.no_grad():
                 _, _, wseg, _ = om(xe, se)
             d_cpu = [oops.dice_average(se[j, 0], wseg[j, 0]) for j in range(nb)]
             d_id = [oops.dice_average(se[j, 0], se[j, 1]) for j in range(nb)]
+            if "dice" not in ev:
+                raise RuntimeError("top flow is not at image resolution: Dice undefined for this predictor")
             dice = {"gpu_mean": round(float(ev["dice"].mean()), 5), "cpu_oracle_mean": round(sum(d_cpu) / nb, 5),
                     "unregistered_mean": round(sum(d_id) / nb, 5), "pairs": nb,
                     "note": "synthetic 4-label masks, weights after the timed steps (random init, no dataset)"}

@@ -188,6 +188,8 @@ def seg_round(x: torch.Tensor) -> torch.Tensor:
 def dice_batch(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
     """Per-sample mean Dice over labels 1..3 for (B, ...) label maps -> (B,) tensor, one launch group."""
     _need_gpu(y_true, y_pred)
+    if y_true.shape[0] != y_pred.shape[0] or y_true.numel() != y_pred.numel():
+        raise RuntimeError(f"dice_batch: label maps differ in size: {tuple(y_true.shape)} vs {tuple(y_pred.shape)}")
     B = y_true.shape[0]
     yt = y_true.contiguous().view(B, -1)
     yp = y_pred.contiguous().view(B, -1)

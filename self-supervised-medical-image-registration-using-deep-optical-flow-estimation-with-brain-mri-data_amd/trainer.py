@@ -205,7 +205,8 @@ class RegistrationTrainer:
         flows, warped, wseg, _ = self.model(x, segs)
         p, c, s, t = ops.OFEloss(flows, warped, x[:, 0:1].contiguous(), *self.loss_hyper)
         out = {"loss": torch.stack((p, c, s, t)), "flow": flows[0]}
-        if segs is not None:
+        if segs is not None and tuple(wseg.shape[2:]) == tuple(segs.shape[2:]):
+            # predictors whose finest flow is not at image resolution (FlowNetC: 64x64) have no Dice in the reference either
             out["dice"] = ops.dice_batch(segs[:, 0:1].float().contiguous(), wseg)
         self.model.train()
         return out

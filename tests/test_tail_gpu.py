@@ -186,3 +186,11 @@ def test_full_size_properties():
     p, c, s, t = mireg.OFEloss([exact], [fixed.clone()], fixed)
     assert c.item() < 1e-6 + (1 - 1 / B) * 100 * 0.05 + 1e-3 and c.item() > (1 - 1 / B) * 100 * 0.05 - 1e-3  # Q6
     assert abs(t.item() - (p + c + s).item()) < 1e-9
+
+
+def test_dice_rejects_mismatched_shapes():
+    import mireg
+    a = torch.zeros(2, 1, 256, 256, device=DEV)
+    b = torch.zeros(2, 1, 64, 64, device=DEV)
+    with pytest.raises(RuntimeError, match="differ in size"):
+        mireg.dice_batch(a, b)
