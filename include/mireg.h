@@ -42,10 +42,14 @@ int mireg_resize_bilinear_bwd(const float* gout, float* gin, int N, int C, int H
                               long isn, long isc, long isp, long osn, long osc, long osp,
                               int align_corners, float beta, hipStream_t stream);
 
+/* Moment tables: per scale MIREG_SUM_SLOTS replicas of 8 doubles {Sx,Sy,Sxy,Sxx,Syy,Scharb,Ssmooth,-}; block b of
+ * a reducing kernel adds into replica b % MIREG_SUM_SLOTS (spreads the float64 atomics over lines), the finalize
+ * kernels sum the replicas.  The caller zeroes the table before the first accumulating launch of a step. */
+#define MIREG_SUM_SLOTS 32
 /* ---- K9 (+K11/K12 partials): opticalFlowReg.stn, models.py:256-268 ----------------------- */
 /* frame is the moving image ALREADY resized to (h,w) (planar B,C,h,w).  When fixed != NULL the
  * kernel also accumulates the six loss moments {Sx,Sy,Sxy,Sxx,Syy,Scharb} of (warped, fixed)
- * into sums[0..5] (doubles, caller zeroes them) -- loss.py:9-14, 52-64 fused into the warp. */
+ * into its replica of sums[MIREG_SUM_SLOTS][8] (entries 0..5) -- loss.py:9-14, 52-64 fused into the warp. */
 int mireg_stn_warp_fwd(const float* flow, long fsb, long fsc, long fsp, const float* frame,
                        const float* fixed, float* warped, double* sums, int B, int C, int h, int w,
                        hipStream_t stream);
@@ -62,7 +66,7 @@ int mireg_smoothness_fwd(const float* flow, long fsb, long fsc, long fsp, double
                          hipStream_t stream);
 int mireg_smoothness_bwd(const float* flow, long fsb, long fsc, long fsp, const float* coef, float* gflow,
                          long gsb, long gsc, long gsp, float beta, int B, int h, int w, hipStream_t stream);
-/* sums: [n][8] doubles {Sx,Sy,Sxy,Sxx,Syy,Scharb,Ssmooth,-}; npix[i] = B*h_i*w_i; out4 = (p,c,s,total)
+/* sums: [n][MIREG_SUM_SLOTS][8] doubles; npix[i] = B*h_i*w_i; out4 = (p,c,s,total)
  * as float64 (the reference returns float64 scalars, loss.py:71-73).  No host synchronisation:
  * the reference's two torch.equal() guards (loss.py:58-60) are evaluated on device. */
 int mireg_ofe_finalize(const double* sums, const long* npix, int n, int B, double lamb_da, double gamma,

@@ -31,87 +31,85 @@ __device__ __forceinline__ float ldf(const __bf16* p) { return (float)*GPTR(cons
 __device__ __forceinline__ void stf(float* p, float v) { *GPTR(float, p) = v; }
 __device__ __forceinline__ void stf(__bf16* p, float v) { *GPTR(__bf16, p) = (__bf16)v; }
 
-// one wave = one (b, y, 32-pixel x tile); loops over dy and the x' tiles the band touches
+// one block = one (b, y, 32-pixel x tile): its 4 waves split the D displacement rows, every wave turns a
+// (dy, x' tile) into one 32x32xC MFMA product and drops the band into the block's LDS output tile [32 px][D*D];
+// the finished tile leaves as whole channel rows (D*D contiguous elements per pixel), i.e. full cache lines.
 template <typename T>
 __global__ void __launch_bounds__(256)
 correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__ f2, long ld2, T* __restrict__ out, long ldo,
                        int B, int H, int W, int C, int c_norm, int R, int s2, float slope) {
-  __shared__ float tile_s[4][32][33];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int D = 2 * R + 1;
+  const int D = 2 * R + 1, DD = D * D;
+  float (*tile)[33] = reinterpret_cast<float (*)[33]>(dyn + wid * 32 * 33 * 4);     // per-wave 32x32 staging
+  T* otile = reinterpret_cast<T*>(dyn + 4 * 32 * 33 * 4);                            // [32][DD]
   const int xt = (W + 31) / 32;
-  const long units = (long)B * H * xt;
   const float inv_c = 1.f / (float)c_norm;
-  float (*tile)[33] = tile_s[wid];
-  for (long u = (long)blockIdx.x * 4 + wid; u < units; u += (long)gridDim.x * 4) {
-    const int x0 = (int)(u % xt) * 32;
-    const int y = (int)((u / xt) % H);
-    const int b = (int)(u / ((long)xt * H));
-    const int xa = x0 + r;                                   // this lane's f1 pixel (A row)
-    const T* a_row = f1 + (((long)b * H + y) * W + min(xa, W - 1)) * ld1;
-    const bool a_ok = xa < W;
-    for (int dyi = 0; dyi < D; ++dyi) {
-      const int yy = y + (dyi - R) * s2;
-      T* o_row = out + (((long)b * H + y) * W) * ldo + dyi * D;
-      if (yy < 0 || yy >= H) {                               // whole displacement row outside f2: zeros
-        for (int e = lane; e < 32 * D; e += 64) {
-          const int px = e / D, dxi = e - px * D;
-          if (x0 + px < W) stf(o_row + (long)(x0 + px) * ldo + dxi, 0.f);
-        }
-        continue;
-      }
-      // x' tiles that intersect [x0 - R*s2, x0 + 31 + R*s2]
-      const int t_lo = max(0, (x0 - R * s2) >> 5), t_hi = min(xt - 1, (x0 + 31 + R * s2) >> 5);
-      // first pass zeroes the band (covers displacements that fall outside [0, W)), later passes fill hits
-      for (int e = lane; e < 32 * D; e += 64) {
-        const int px = e / D, dxi = e - px * D;
-        const int xx = x0 + px + (dxi - R) * s2;
-        if (x0 + px < W && (xx < 0 || xx >= W)) stf(o_row + (long)(x0 + px) * ldo + dxi, 0.f);
-      }
-      for (int t = t_lo; t <= t_hi; ++t) {
-        const int xb = t * 32 + r;                             // this lane's f2 pixel (B column)
-        const T* b_row = f2 + (((long)b * H + yy) * W + min(xb, W - 1)) * ld2;
-        const bool b_ok = xb < W;
-        f32x16 acc;
+  const int u = blockIdx.x;
+  const int x0 = (u % xt) * 32;
+  const int y = (u / xt) % H;
+  const int b = u / (xt * H);
+  const int xa = x0 + r;                                     // this lane's f1 pixel (A row)
+  const T* a_row = f1 + (((long)b * H + y) * W + min(xa, W - 1)) * ld1;
+  const bool a_ok = xa < W;
+  for (int e = threadIdx.x; e < 32 * DD; e += 256) otile[e] = (T)0.f;   // out-of-image displacements stay zero
+  __syncthreads();
+  for (int dyi = wid; dyi < D; dyi += 4) {
+    const int yy = y + (dyi - R) * s2;
+    if (yy < 0 || yy >= H) continue;
+    const int t_lo = max(0, (x0 - R * s2) >> 5), t_hi = min(xt - 1, (x0 + 31 + R * s2) >> 5);
+    for (int t = t_lo; t <= t_hi; ++t) {
+      const int xb = t * 32 + r;                             // this lane's f2 pixel (B column)
+      const T* b_row = f2 + (((long)b * H + yy) * W + min(xb, W - 1)) * ld2;
+      const bool b_ok = xb < W;
+      f32x16 acc;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        if constexpr (sizeof(T) == 2) {
-          for (int k = 0; k < C; k += 16) {                    // C % 8 == 0; a trailing half step is zero-filled
-            const int kk = k + 8 * h;
-            uint4 av = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
-            if (a_ok && kk < C) av = *GPTR(const uint4, a_row + kk);
-            if (b_ok && kk < C) bv = *GPTR(const uint4, b_row + kk);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
-          }
-        } else {
-          for (int k = 0; k < C; k += 8) {                     // lane (r,h) feeds K slots k+4h..k+4h+3, one per MFMA
-            const int kk = k + 4 * h;
-            float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
-            if (a_ok && kk < C) av = *GPTR(const float4, a_row + kk);
-            if (b_ok && kk < C) bv = *GPTR(const float4, b_row + kk);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
-          }
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll 4
+        for (int k = 0; k < C; k += 16) {                    // C % 8 == 0; a trailing half step is zero-filled
+          const int kk = k + 8 * h;
+          uint4 av = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
+          if (a_ok && kk < C) av = *GPTR(const uint4, a_row + kk);
+          if (b_ok && kk < C) bv = *GPTR(const uint4, b_row + kk);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
         }
-        // acc[e] = <f1[x0 + row], f2[32 t + col]>, col = lane&31, row = (e&3) + 8*(e>>2) + 4*h
+      } else {
+#pragma unroll 2
+        for (int k = 0; k < C; k += 8) {                     // lane (r,h) feeds K slots k+4h..k+4h+3, one per MFMA
+          const int kk = k + 4 * h;
+          float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+          if (a_ok && kk < C) av = *GPTR(const float4, a_row + kk);
+          if (b_ok && kk < C) bv = *GPTR(const float4, b_row + kk);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        }
+      }
+      // acc[e] = <f1[x0 + row], f2[32 t + col]>, col = lane&31, row = (e&3) + 8*(e>>2) + 4*h
 #pragma unroll
-        for (int e = 0; e < 16; ++e) tile[(e & 3) + 8 * (e >> 2) + 4 * h][r] = acc[e];
-        __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < 32 * D; e += 64) {
-          const int px = e / D, dxi = e - px * D;
-          const int xx = x0 + px + (dxi - R) * s2;             // f2 pixel of this displacement
-          if (x0 + px < W && xx >= t * 32 && xx < t * 32 + 32 && xx < W) {
+      for (int e = 0; e < 16; ++e) tile[(e & 3) + 8 * (e >> 2) + 4 * h][r] = acc[e];
+      __builtin_amdgcn_wave_barrier();
+      for (int px = h; px < 32; px += 2) {                   // lanes 0..31 of each half walk dx for one pixel
+        if (r < D) {
+          const int xx = x0 + px + (r - R) * s2;             // f2 pixel of displacement dxi = r
+          if (xx >= t * 32 && xx < t * 32 + 32 && xx < W) {
             float v = tile[px][xx - t * 32] * inv_c;
             v = v > 0.f ? v : v * slope;
-            stf(o_row + (long)(x0 + px) * ldo + dxi, v);
+            otile[px * DD + dyi * D + r] = (T)v;
           }
         }
-        __builtin_amdgcn_wave_barrier();
       }
+      __builtin_amdgcn_wave_barrier();
     }
+  }
+  __syncthreads();
+  T* o_base = out + (((long)b * H + y) * W + x0) * ldo;
+  for (int e = threadIdx.x; e < 32 * DD; e += 256) {
+    const int px = e / DD, ch = e - px * DD;
+    if (x0 + px < W) *GPTR(T, o_base + (long)px * ldo + ch) = otile[e];
   }
 }
 
@@ -265,13 +263,15 @@ int mireg_correlation_fwd(const void* f1, long ld1, const void* f2, long ld2, vo
   const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
   MIREG_CHECK_ARG(C % V == 0 && ld1 % V == 0 && ld2 % V == 0 && (uintptr_t)f1 % 16 == 0 && (uintptr_t)f2 % 16 == 0);
   const long units = (long)B * H * ((W + 31) / 32);
-  long g = (units + 3) / 4;
-  if (g > 4096) g = 4096;
+  MIREG_CHECK_ARG(units < (1L << 30));
+  const long g = units;
   const int R = max_displacement / stride2;
+  const int DD = (2 * R + 1) * (2 * R + 1);
+  const size_t lds = 4 * 32 * 33 * 4 + (size_t)32 * DD * (dtype == MIREG_DTYPE_BF16 ? 2 : 4);
   if (dtype == MIREG_DTYPE_BF16)
-    hipLaunchKernelGGL((correlation_fwd_kernel<__bf16>), dim3((unsigned)g), dim3(256), 0, stream, (const __bf16*)f1, ld1, (const __bf16*)f2, ld2, (__bf16*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
+    hipLaunchKernelGGL((correlation_fwd_kernel<__bf16>), dim3((unsigned)g), dim3(256), lds, stream, (const __bf16*)f1, ld1, (const __bf16*)f2, ld2, (__bf16*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
   else if (dtype == MIREG_DTYPE_F32)
-    hipLaunchKernelGGL((correlation_fwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)f1, ld1, (const float*)f2, ld2, (float*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
+    hipLaunchKernelGGL((correlation_fwd_kernel<float>), dim3((unsigned)g), dim3(256), lds, stream, (const float*)f1, ld1, (const float*)f2, ld2, (float*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
   else return MIREG_ERR_ARG;
   MIREG_LAUNCH_RET();
 }

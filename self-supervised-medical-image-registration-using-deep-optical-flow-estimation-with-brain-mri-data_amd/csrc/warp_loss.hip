@@ -19,6 +19,7 @@ using namespace mireg;
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kSlots = MIREG_SUM_SLOTS;   // moment tables are replicated: block b adds into slot b % kSlots (no hot line)
 
 // ---------------------------------------------------------------------------------------------
 // bilinear source index, identical op order to ATen's area_pixel_compute_source_index
@@ -182,8 +183,9 @@ stn_warp_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp
   if (SUMS) {
     block_sum<6>(acc, red);
     if (threadIdx.x == 0) {
+      double* dst = sums + (blockIdx.x % kSlots) * 8;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) atomicAdd(&sums[i], (double)acc[i]);
+      for (int i = 0; i < 6; ++i) atomicAdd(&dst[i], (double)acc[i]);
     }
   }
 }
@@ -246,8 +248,9 @@ loss_partials_kernel(const float* __restrict__ warped, const float* __restrict__
   }
   block_sum<6>(acc, red);
   if (threadIdx.x == 0) {
+    double* dst = sums + (blockIdx.x % kSlots) * 8;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) atomicAdd(&sums[i], (double)acc[i]);
+    for (int i = 0; i < 6; ++i) atomicAdd(&dst[i], (double)acc[i]);
   }
 }
 
@@ -282,7 +285,7 @@ smooth_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, 
     }
   }
   block_sum<1>(acc, red);
-  if (threadIdx.x == 0) atomicAdd(sum, (double)acc[0]);
+  if (threadIdx.x == 0) atomicAdd(sum + (blockIdx.x % kSlots) * 8, (double)acc[0]);
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -313,6 +316,14 @@ smooth_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, 
 // ---------------------------------------------------------------------------------------------
 // OFEloss finalisation, float64 like the reference (its weights are a float64 tensor).
 // sums: [n][8] = {Sx, Sy, Sxy, Sxx, Syy, Scharb, Ssmooth, -};  npix[i] = B*h_i*w_i
+__device__ __forceinline__ void gather_slots(const double* __restrict__ sums, int scale, double (&q)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = 0.0;
+  for (int sl = 0; sl < kSlots; ++sl)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) q[i] += sums[((long)scale * kSlots + sl) * 8 + i];
+}
+
 __device__ __forceinline__ void ncc_moments(const double* s, double N, double& sxx, double& syy, double& sxy,
                                             double& mx, double& my, bool& degenerate) {
   mx = s[0] / N; my = s[1] / N;
@@ -328,7 +339,8 @@ __global__ void ofe_finalize_kernel(const double* __restrict__ sums, const long*
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double p = 0, c = 0, s = 0;
   for (int i = 0; i < n; ++i) {
-    const double* q = sums + 8 * i;
+    double q[8];
+    gather_slots(sums, i, q);
     const double wgt = 0.05 * (double)(i + 1);
     double sxx, syy, sxy, mx, my; bool deg;
     ncc_moments(q, (double)npix[i], sxx, syy, sxy, mx, my, deg);
@@ -347,7 +359,8 @@ __global__ void ofe_bwd_coef_kernel(const double* __restrict__ sums, const long*
                                     float* __restrict__ coef) {
   const int i = threadIdx.x;
   if (blockIdx.x != 0 || i >= n) return;
-  const double* q = sums + 8 * i;
+  double q[8];
+  gather_slots(sums, i, q);
   const double wgt = 0.05 * (double)(i + 1);
   const double gp = g4[0] + g4[3], gc = g4[1] + g4[3], gs = g4[2] + g4[3];
   double sxx, syy, sxy, mx, my; bool deg;
@@ -445,12 +458,11 @@ int mireg_stn_warp_fwd(const float* flow, long fsb, long fsc, long fsp, const fl
                    ((uintptr_t)flow % 16 == 0) && ((uintptr_t)warped % 16 == 0) && (!fixed || (uintptr_t)fixed % 16 == 0);
   const long npix = (long)B * h * w;
   if (vec) {
-    // kernels that end in 6 double atomics per block keep the grid at ~1 block per CU (contention on one line)
-    const int g = sums ? grid_for(npix / 4, 256) : grid_for(npix / 4);
+    const int g = grid_for(npix / 4);
     if (sums) hipLaunchKernelGGL((stn_warp_fwd_kernel<4, true>), dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame, fixed, warped, sums, B, C, h, w);
     else hipLaunchKernelGGL((stn_warp_fwd_kernel<4, false>), dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame, fixed, warped, sums, B, C, h, w);
   } else {
-    const int g = sums ? grid_for(npix, 256) : grid_for(npix);
+    const int g = grid_for(npix);
     if (sums) hipLaunchKernelGGL((stn_warp_fwd_kernel<1, true>), dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame, fixed, warped, sums, B, C, h, w);
     else hipLaunchKernelGGL((stn_warp_fwd_kernel<1, false>), dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame, fixed, warped, sums, B, C, h, w);
   }
@@ -469,7 +481,7 @@ int mireg_stn_warp_bwd(const float* flow, long fsb, long fsc, long fsp, const fl
 int mireg_loss_partials(const float* warped, const float* fixed, double* sums, long n, hipStream_t stream) {
   MIREG_CHECK_ARG(warped && fixed && sums && n > 0);
   MIREG_CHECK_ARG((uintptr_t)warped % 16 == 0 && (uintptr_t)fixed % 16 == 0);
-  hipLaunchKernelGGL(loss_partials_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(kThreads), 0, stream, warped, fixed, sums, n);
+  hipLaunchKernelGGL(loss_partials_kernel, dim3(grid_for(n / 4 + 1)), dim3(kThreads), 0, stream, warped, fixed, sums, n);
   MIREG_LAUNCH_RET();
 }
 
@@ -483,7 +495,7 @@ int mireg_loss_bwd(const float* warped, const float* fixed, const float* coef, f
 int mireg_smoothness_fwd(const float* flow, long fsb, long fsc, long fsp, double* sum, int B, int h, int w,
                          hipStream_t stream) {
   MIREG_CHECK_ARG(flow && sum && B > 0 && h > 0 && w > 0);
-  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(grid_for((long)B * h * w, 256)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, sum, B, h, w);
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(grid_for((long)B * h * w)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, sum, B, h, w);
   MIREG_LAUNCH_RET();
 }
 

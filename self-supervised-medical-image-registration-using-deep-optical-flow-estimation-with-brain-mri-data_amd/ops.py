@@ -13,6 +13,7 @@ import torch
 from . import _lib
 
 F32 = torch.float32
+SLOTS = 32          # MIREG_SUM_SLOTS: replicas of every moment row (include/mireg.h)
 
 
 def _stream() -> int:
@@ -114,7 +115,7 @@ class _OFELossFn(torch.autograd.Function):
         _need_gpu(fixed, *flows, *warped)
         dev = fixed.device
         B = fixed.shape[0]
-        sums = torch.zeros(n, 8, device=dev, dtype=torch.float64)
+        sums = torch.zeros(n, SLOTS, 8, device=dev, dtype=torch.float64)
         npix = torch.tensor([w.numel() for w in warped], dtype=torch.int64).to(dev, non_blocking=True)
         fixed_rs, wcs, fviews = [], [], []
         st = _stream()
@@ -125,7 +126,7 @@ class _OFELossFn(torch.autograd.Function):
             fr = fr.contiguous()
             _lib.call("mireg_loss_partials", wi.data_ptr(), fr.data_ptr(), sums[i].data_ptr(), wi.numel(), st)
             fl, sb, sc, sp = _flow_view(flows[i])
-            _lib.call("mireg_smoothness_fwd", fl.data_ptr(), sb, sc, sp, sums[i, 6:].data_ptr(), B, fl.shape[2],
+            _lib.call("mireg_smoothness_fwd", fl.data_ptr(), sb, sc, sp, sums[i, 0, 6:].data_ptr(), B, fl.shape[2],
                       fl.shape[3], st)
             fixed_rs.append(fr)
             wcs.append(wi)

@@ -20,6 +20,7 @@ import torch.nn as nn
 from . import _lib
 from . import dist as mdist
 from .engine import AdamJob, F32, _stream, upload_table
+from .ops import SLOTS
 
 
 def flatten_parameters(module: nn.Module) -> torch.Tensor:
@@ -50,7 +51,7 @@ class FusedRegLoss:
         self.warped = [z(B, 1, h, w) for h, w in sizes]
         self.gwarped = [z(B, 1, h, w) for h, w in sizes]
         self.gflow = [z(B, 2, h, w) for h, w in sizes]
-        self.sums = torch.zeros(n, 8, device=device, dtype=torch.float64)
+        self.sums = torch.zeros(n, SLOTS, 8, device=device, dtype=torch.float64)
         self.npix = torch.tensor([B * h * w for h, w in sizes], dtype=torch.int64, device=device)
         self.out4 = torch.zeros(4, device=device, dtype=torch.float64)
         self.g4 = torch.tensor([0.0, 0.0, 0.0, 1.0], device=device, dtype=torch.float64)
@@ -72,7 +73,7 @@ class FusedRegLoss:
             sp = sx if w > 1 else (sy if h > 1 else 1)
             _lib.call("mireg_stn_warp_fwd", f.data_ptr(), sb, sc, sp, self.moving_r[i].data_ptr(),
                       self.fixed_r[i].data_ptr(), self.warped[i].data_ptr(), self.sums[i].data_ptr(), B, 1, h, w, st)
-            _lib.call("mireg_smoothness_fwd", f.data_ptr(), sb, sc, sp, self.sums[i, 6:].data_ptr(), B, h, w, st)
+            _lib.call("mireg_smoothness_fwd", f.data_ptr(), sb, sc, sp, self.sums[i, 0, 6:].data_ptr(), B, h, w, st)
         return self.sums
 
     def _npix(self, B_global: Optional[int]) -> torch.Tensor:
