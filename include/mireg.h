@@ -200,7 +200,13 @@ int mireg_correlation_bwd(const void* g, long ldg, const void* f1, long ld1, con
 int mireg_pwc_warp_fwd(const void* x, long ldx, const float* flow, long ldf, float flow_scale, void* out, long ldo,
                        int B, int H, int W, int C, int dtype, hipStream_t stream);
 /* concat staging for producers that cannot write in place (PWCNet.py:217: cat(corr, c1, up_flow, up_feat)) */
-int mireg_copy_channels(const void* src, long ld_s, void* dst, long ld_d, long M, int C, int dtype, hipStream_t stream);
+int mireg_copy_channels(const void* src, long ld_s, void* dst, long ld_d, long M, int C, int accumulate, int dtype,
+                        hipStream_t stream);
+/* backward of the PWC warp: dx32 (fp32 NHWC scratch, zeroed by the caller) and dflow (fp32 [pix][lddf], zeroed by the
+ * caller) receive atomic adds; the validity mask carries no gradient (it is overwritten in place in the reference). */
+int mireg_pwc_warp_bwd(const void* x, long ldx, const float* flow, long ldf, float flow_scale, const void* g, long ldg,
+                       float* dx32, long lddx, float* dflow, long lddf, int B, int H, int W, int C, int dtype,
+                       hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -231,14 +231,70 @@ pwc_warp_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__
   }
 }
 
-// dst[m][0..C) = src[m][0..C)  (concat staging where a producer cannot write in place; any channel offset)
+// PWC warp backward (mask is a constant of the graph: PWCNet.py:174-177 overwrites it in place):
+//   dx[tap_t][c] += m * w_t * g[c]            (fp32 atomics into a zeroed NHWC scratch, cast/added by the caller)
+//   dflow       += scale * W/(W-1) * m * sum_c g[c] * sum_t dw_t/dpx * x[tap_t][c]     (likewise for y)
 template <typename T>
 __global__ void __launch_bounds__(256)
-copy_channels_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd, long M, int C) {
+pwc_warp_bwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ flow, long ldf_, float flow_scale,
+                    const T* __restrict__ g, long ldg, float* __restrict__ dx32, long lddx, float* __restrict__ dflow, long lddf,
+                    int B, int H, int W, int C) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int cpr = C / V;
+  const long total = (long)B * H * W * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)
+    const long pix = i / cpr;
+    const int c0 = (int)(i - pix * cpr) * V;
+    const int xq = (int)(pix % W), yq = (int)((pix / W) % H);
+    const long img = pix / ((long)W * H);
+    const float u = flow[pix * ldf_] * flow_scale, v = flow[pix * ldf_ + 1] * flow_scale;
+    const float gx = 2.0f * ((float)xq + u) / (float)max(W - 1, 1) - 1.0f;
+    const float gy = 2.0f * ((float)yq + v) / (float)max(H - 1, 1) - 1.0f;
+    const float px = ((gx + 1.f) * (float)W - 1.f) / 2.f, py = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    const float fx = floorf(px), fy = floorf(py);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = px - fx, wy1 = py - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    float msk = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+      if (xi >= 0 && xi < W && yi >= 0 && yi < H) msk += ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
+    }
+    if (msk < 0.9999f) continue;                         // masked pixel: no gradient at all
+    float gv[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) gv[q] = ldf(g + pix * ldg + c0 + q);
+    float dpx = 0.f, dpy = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+      if (xi < 0 || xi >= W || yi < 0 || yi >= H) continue;
+      const float wx = (t & 1) ? wx1 : wx0, wy = (t >> 1) ? wy1 : wy0;
+      const float dwx = (t & 1) ? 1.f : -1.f, dwy = (t >> 1) ? 1.f : -1.f;
+      const long tp = ((img * H + yi) * W + xi);
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const float xv = ldf(x + tp * ldx + c0 + q);
+        atomicAdd(dx32 + tp * lddx + c0 + q, gv[q] * wx * wy);
+        dpx += gv[q] * xv * dwx * wy;
+        dpy += gv[q] * xv * wx * dwy;
+      }
+    }
+    atomicAdd(dflow + pix * lddf, dpx * flow_scale * (float)W / (float)max(W - 1, 1));
+    atomicAdd(dflow + pix * lddf + 1, dpy * flow_scale * (float)H / (float)max(H - 1, 1));
+  }
+}
+
+// dst[m][0..C) (+)= src[m][0..C)  (concat staging where a producer cannot write in place; any channel offset)
+template <typename T>
+__global__ void __launch_bounds__(256)
+copy_channels_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd, long M, int C, int accumulate) {
   const long total = M * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / C; const int c = (int)(i - m * C);
-    *GPTR(T, dst + m * ldd + c) = *GPTR(const T, src + m * lds_ + c);
+    const float v = ldf(src + m * lds_ + c) + (accumulate ? ldf(dst + m * ldd + c) : 0.f);
+    stf(dst + m * ldd + c, v);
   }
 }
 
@@ -246,12 +302,28 @@ copy_channels_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, 
 
 extern "C" {
 
-int mireg_copy_channels(const void* src, long ld_s, void* dst, long ld_d, long M, int C, int dtype, hipStream_t stream) {
+int mireg_pwc_warp_bwd(const void* x, long ldx, const float* flow, long ldf_, float flow_scale, const void* g, long ldg,
+                       float* dx32, long lddx, float* dflow, long lddf, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(x && flow && g && dx32 && dflow && B > 0 && H > 0 && W > 0 && C > 0 && ldf_ >= 2 && lddf >= 2);
+  const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
+  MIREG_CHECK_ARG(C % V == 0);
+  const long total = (long)B * H * W * (C / V);
+  long gr = (total + 255) / 256;
+  if (gr > 4096) gr = 4096;
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((pwc_warp_bwd_kernel<__bf16>), dim3((unsigned)gr), dim3(256), 0, stream, (const __bf16*)x, ldx, flow, ldf_, flow_scale, (const __bf16*)g, ldg, dx32, lddx, dflow, lddf, B, H, W, C);
+  else if (dtype == MIREG_DTYPE_F32)
+    hipLaunchKernelGGL((pwc_warp_bwd_kernel<float>), dim3((unsigned)gr), dim3(256), 0, stream, (const float*)x, ldx, flow, ldf_, flow_scale, (const float*)g, ldg, dx32, lddx, dflow, lddf, B, H, W, C);
+  else return MIREG_ERR_ARG;
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_copy_channels(const void* src, long ld_s, void* dst, long ld_d, long M, int C, int accumulate, int dtype, hipStream_t stream) {
   MIREG_CHECK_ARG(src && dst && M > 0 && C > 0);
   long g = (M * C + 255) / 256;
   if (g > 4096) g = 4096;
-  if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((copy_channels_kernel<__bf16>), dim3((unsigned)g), dim3(256), 0, stream, (const __bf16*)src, ld_s, (__bf16*)dst, ld_d, M, C);
-  else hipLaunchKernelGGL((copy_channels_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, ld_s, (float*)dst, ld_d, M, C);
+  if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((copy_channels_kernel<__bf16>), dim3((unsigned)g), dim3(256), 0, stream, (const __bf16*)src, ld_s, (__bf16*)dst, ld_d, M, C, accumulate);
+  else hipLaunchKernelGGL((copy_channels_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, ld_s, (float*)dst, ld_d, M, C, accumulate);
   MIREG_LAUNCH_RET();
 }
 

@@ -387,6 +387,8 @@ class ConvLayer:
     def run_bias_grad(self, dy: View, accumulate: bool = False) -> None:
         if self.bias is None:
             return
+        if self.grad_b is None:
+            self.grad_b = torch.zeros_like(self.bias, dtype=F32)
         _lib.call("mireg_colsum", dy.ptr, dy.ld, dy.rows, dy.C, self.grad_b.data_ptr(), int(accumulate), self.ws.code,
                   _stream())
 

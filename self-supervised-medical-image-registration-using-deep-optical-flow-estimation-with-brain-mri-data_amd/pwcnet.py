@@ -5,7 +5,8 @@ input) in both train and eval mode.  Every torch.cat of the DenseNet
 replaced by channel-offset writes: each level owns ONE buffer laid out
     [conv_4 32 | conv_3 64 | conv_2 96 | conv_1 128 | conv_0 128 | corr 81 | c1 C_l | up_flow 2 | up_feat 2]
 so that conv_j reads the suffix that starts at its own output's end (all suffix offsets are multiples of 32).
-Forward is implemented; the backward (correlation / warp backward kernels) is scheduled next.
+The backward zeroes every gradient buffer once and lets all producers accumulate (dense connections fan gradients
+into overlapping channel ranges); cost-volume and warp backward run on csrc/correlation.hip.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ import torch.nn as nn
 
 from . import _lib
 from .correlation import Correlation, correlation_views, pwc_warp_views
-from .engine import F32, View, _stream, cast_from_f32, nchw_to_view
+from .engine import F32, View, _stream, cast_from_f32, lrelu_bwd, nchw_to_view
 from .flownets import PredictorEngineBase
 
 SLOPE = 0.1
@@ -48,7 +49,7 @@ class PWCEngine(PredictorEngineBase):
         self.hs = hs
         for lvl in range(1, 7):
             for i, n in enumerate(PYR_NAMES[lvl]):
-                self.add_conv(n, getattr(m, n)[0], 2 if i == 0 else 1, 1)
+                self.add_conv(n, getattr(m, n)[0], 2 if i == 0 else 1, 1, uses=2)     # siamese: one wgrad slot per stream
         for lvl in (6, 5, 4, 3, 2):
             for j in range(5):
                 self.add_conv(f"conv{lvl}_{j}", getattr(m, f"conv{lvl}_{j}")[0], 1, 1)
@@ -71,6 +72,7 @@ class PWCEngine(PredictorEngineBase):
         self.upflow32 = {lvl: new(B, *hs[lvl], 2, dtype=F32, pad=2) for lvl in (5, 4, 3, 2)}
         self.dc = [new(B, *hs[2], c) for c, _ in DC]
         self.dc7 = new(B, *hs[2], 2)
+        self.grads_ready = False
 
     def forward(self, x: torch.Tensor, training: bool) -> List[torch.Tensor]:
         L, code, st = self.layers, self.ws.code, _stream()
@@ -98,7 +100,7 @@ class PWCEngine(PredictorEngineBase):
                 pwc_warp_views(c2, self.upflow32[lvl], FLOW_SCALE[lvl], self.warped[lvl], code)
                 correlation_views(c1, self.warped[lvl], X.slice(BASE, self.nd), FEAT_C[lvl], self.md, 1, SLOPE, code)
                 _lib.call("mireg_copy_channels", c1.ptr, c1.ld, X.slice(BASE + self.nd, FEAT_C[lvl]).ptr, X.ld, c1.rows,
-                          FEAT_C[lvl], code, st)
+                          FEAT_C[lvl], 0, code, st)
             for j in range(5):                                 # DenseNet estimator: conv_j reads the suffix, writes in front
                 off, cout = DENSE_OFF[j], DENSE[j]
                 L[f"conv{lvl}_{j}"].run_fwd_form(X.slice(off + cout, X.C - off - cout), X.slice(off, cout), slope=SLOPE)
@@ -122,9 +124,130 @@ class PWCEngine(PredictorEngineBase):
         L["deconv1"].run_dgrad_form(self.flowT[1], None, y32=self.flow32[0], bias=True)
         return [self.flow32[l].nchw() for l in range(0, 7)]
 
+    # ------------------------------------------------------------------------------------------------
+    def _ensure_grad_buffers(self) -> None:
+        if self.grads_ready:
+            return
+        new, hs, B = self.ws.new, self.hs, self.B
+        z = lambda v: new(v.B, v.H, v.W, v.C)
+        self.dx = {lvl: z(v) for lvl, v in self.x.items()}
+        self.dpyr = {k: z(v) for k, v in self.pyr.items()}
+        self.dwarped = {lvl: z(v) for lvl, v in self.warped.items()}
+        self.dflowT = {lvl: new(B, *hs[lvl], 2) for lvl in range(0, 7)}
+        self.dupflowT = {lvl: new(B, *hs[lvl], 2) for lvl in (5, 4, 3, 2)}
+        self.dupfeatT = {lvl: new(B, *hs[lvl], 2) for lvl in (5, 4, 3, 2)}
+        self.dupflow32 = {lvl: new(B, *hs[lvl], 2, dtype=F32, pad=2) for lvl in (5, 4, 3, 2)}
+        self.dx32 = {lvl: new(B, *hs[lvl], FEAT_C[lvl], dtype=F32) for lvl in (5, 4, 3, 2)}
+        self.ddc = [z(v) for v in self.dc]
+        self._zero_list = ([v.buf for v in self.dx.values()] + [v.buf for v in self.dpyr.values()] +
+                           [v.buf for v in self.dwarped.values()] + [v.buf for v in self.dupflow32.values()] +
+                           [v.buf for v in self.dx32.values()] + [v.buf for v in self.ddc])
+        self.grads_ready = True
+
+    def _conv_bwd(self, name: str, src: View, out: View, dout: View, dsrc, slot: int = 0, act: bool = True) -> None:
+        """conv (+bias) (+LeakyReLU) backward; every gradient buffer was zeroed, so dgrad always accumulates."""
+        lay = self.layers[name]
+        if act:
+            lrelu_bwd(dout, out, SLOPE, self.ws)
+        lay.run_bias_grad(dout, accumulate=slot > 0)
+        self.wgrad_async(lay, src, dout, slot)
+        if dsrc is not None:
+            lay.run_dgrad_form(dout, dsrc, accumulate=True)
+
+    def _deconv_bwd(self, name: str, g_fine: View, x_coarse: View, dx_coarse: View) -> None:
+        """ConvTranspose2d(k4,s2,p1) backward: g_fine = grad wrt its (2x larger) output."""
+        lay = self.layers[name]
+        lay.run_bias_grad(g_fine)
+        self.wgrad_async(lay, g_fine, x_coarse)
+        lay.run_fwd_form(g_fine, dx_coarse, bias=False, accumulate=True)
+
     def backward(self, gflows) -> None:
-        raise NotImplementedError("PWCDCNet backward (correlation / warp backward kernels) is not implemented yet; "
-                                  "see DESIGN.md section 9")
+        """gflows: gradients wrt (flow0 .. flow6) as (B,2,h,w) fp32 or None."""
+        self._ensure_grad_buffers()
+        L, code, st, B = self.layers, self.ws.code, _stream(), self.B
+        g = list(gflows) + [None] * (7 - len(gflows))
+        for buf in self._zero_list:
+            buf.zero_()
+        for lvl in range(0, 7):                                   # loss gradients of the seven flows
+            if g[lvl] is None:
+                self.dflowT[lvl].buf.zero_()
+            else:
+                nchw_to_view(g[lvl].contiguous(), 0, 2, self.dflowT[lvl])
+        # flow0 = deconv1(flow1), flow1 = deconv2(flow2)
+        self._deconv_bwd("deconv1", self.dflowT[0], self.flowT[1], self.dflowT[1])
+        self._deconv_bwd("deconv2", self.dflowT[1], self.flowT[2], self.dflowT[2])
+        # flow2 = predict_flow2(x2) + dc_conv7(dc_conv6(...dc_conv1(x2)))
+        dX2 = self.dx[2]
+        self._conv_bwd("dc_conv7", self.dc[5], self.dc7, self.dflowT[2], self.ddc[5], act=False)
+        for i in range(6, 0, -1):
+            src, dsrc = (self.dc[i - 2], self.ddc[i - 2]) if i > 1 else (self.x[2], dX2)
+            self._conv_bwd(f"dc_conv{i}", src, self.dc[i - 1], self.ddc[i - 1], dsrc)
+        feat = lambda lvl, s: self.pyr[(lvl, s, 2)]
+        dfeat = lambda lvl, s: self.dpyr[(lvl, s, 2)]
+        for lvl in (2, 3, 4, 5, 6):
+            X, dX = self.x[lvl], self.dx[lvl]
+            # predict_flow{lvl}: dflowT[lvl] now holds loss grad + everything pushed up from the finer level
+            self._conv_bwd(f"predict_flow{lvl}", X, self.flowT[lvl], self.dflowT[lvl], dX, act=False)
+            for j in range(4, -1, -1):                            # DenseNet estimator, last conv first
+                off, cout = DENSE_OFF[j], DENSE[j]
+                self._conv_bwd(f"conv{lvl}_{j}", X.slice(off + cout, X.C - off - cout), X.slice(off, cout),
+                               dX.slice(off, cout), dX.slice(off + cout, X.C - off - cout))
+            gcorr = dX.slice(BASE, self.nd)
+            lrelu_bwd(gcorr, X.slice(BASE, self.nd), SLOPE, self.ws)
+            c1, c2 = feat(lvl, "a"), feat(lvl, "b")
+            cp = (FEAT_C[lvl] + 7) // 8 * 8
+            if lvl == 6:
+                d1, d2 = dfeat(6, "a"), dfeat(6, "b")
+                _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, c1.ptr, c1.ld, c2.ptr, c2.ld, d1.ptr, d1.ld, d2.ptr,
+                          d2.ld, B, c1.H, c1.W, cp, FEAT_C[6], self.md, 1, 1, 1, code, st)
+                continue
+            wv, dw, d1 = self.warped[lvl], self.dwarped[lvl], dfeat(lvl, "a")
+            _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, c1.ptr, c1.ld, wv.ptr, wv.ld, d1.ptr, d1.ld, dw.ptr, dw.ld,
+                      B, c1.H, c1.W, cp, FEAT_C[lvl], self.md, 1, 1, 1, code, st)
+            # c1 also sits in the concat
+            gc1 = dX.slice(BASE + self.nd, FEAT_C[lvl])
+            _lib.call("mireg_copy_channels", gc1.ptr, gc1.ld, d1.ptr, d1.ld, d1.rows, FEAT_C[lvl], 1, code, st)
+            # warp backward -> d c2 (fp32 scatter) and d up_flow (fp32)
+            dx32, duf32, d2 = self.dx32[lvl], self.dupflow32[lvl], dfeat(lvl, "b")
+            _lib.call("mireg_pwc_warp_bwd", c2.ptr, c2.ld, self.upflow32[lvl].ptr, self.upflow32[lvl].ld, FLOW_SCALE[lvl],
+                      dw.ptr, dw.ld, dx32.ptr, dx32.ld, duf32.ptr, duf32.ld, B, c2.H, c2.W, FEAT_C[lvl], code, st)
+            cast_from_f32(d2.slice(0, FEAT_C[lvl]), dx32.slice(0, FEAT_C[lvl]), 1.0, 1.0)
+            # up_flow / up_feat gradients: aligned 2-channel staging buffers (the concat slices sit at odd offsets)
+            o = BASE + self.nd + FEAT_C[lvl]
+            guf, gft = self.dupflowT[lvl], self.dupfeatT[lvl]
+            _lib.call("mireg_copy_channels", dX.slice(o, 2).ptr, dX.ld, guf.ptr, guf.ld, guf.rows, 2, 0, code, st)
+            cast_from_f32(guf, duf32, 1.0, 1.0)
+            _lib.call("mireg_copy_channels", dX.slice(o + 2, 2).ptr, dX.ld, gft.ptr, gft.ld, gft.rows, 2, 0, code, st)
+            self._deconv_bwd(f"deconv{lvl + 1}", guf, self.flowT[lvl + 1], self.dflowT[lvl + 1])
+            self._deconv_bwd(f"upfeat{lvl + 1}", gft, self.x[lvl + 1], self.dx[lvl + 1])
+        # siamese pyramid, coarse -> fine, one wgrad slot per stream
+        for slot, s_ in enumerate("ab"):
+            for lvl in range(6, 0, -1):
+                for i in (2, 1, 0):
+                    if i > 0:
+                        src, dsrc = self.pyr[(lvl, s_, i - 1)], self.dpyr[(lvl, s_, i - 1)]
+                    elif lvl > 1:
+                        src, dsrc = self.pyr[(lvl - 1, s_, 2)], self.dpyr[(lvl - 1, s_, 2)]
+                    else:
+                        src, dsrc = self.img[s_], None
+                    self._conv_bwd(PYR_NAMES[lvl][i], src, self.pyr[(lvl, s_, i)], self.dpyr[(lvl, s_, i)], dsrc, slot)
+        self.join_side()
+        self.unpack_grads()
+
+
+class _PWCFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        eng = module.engine_for(x)
+        ctx.eng, ctx.module = eng, module
+        return tuple(eng.forward(x, module.training))
+
+    @staticmethod
+    def backward(ctx, *g):
+        ctx.eng.backward(g)
+        table = ctx.eng.param_grads()
+        grads = tuple(table[id(p)].clone() if id(p) in table else None for p in ctx.module.parameters())
+        return (None, None) + grads
 
 
 class PWCDCNet(nn.Module):
@@ -182,6 +305,5 @@ class PWCDCNet(nn.Module):
 
     def forward(self, x):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("PWCDCNet training (backward) is not implemented yet; wrap inference in "
-                                      "torch.no_grad() (DESIGN.md section 9)")
+            return tuple(_PWCFn.apply(self, x.float(), *self.parameters()))
         return tuple(self.engine_for(x).forward(x.float(), self.training))

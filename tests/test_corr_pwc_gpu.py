@@ -165,3 +165,52 @@ def test_flownetc_training_step_matches_oracle():
         worst = max(worst, rel)
         assert rel < 2e-2, (k, rel)
     print("worst relative L2 gradient error", worst)
+
+
+def test_pwc_warp_backward_vs_autograd():
+    from mireg import _lib
+    from mireg.engine import Workspace, _stream
+    ws = Workspace(torch.device(DEV), torch.float32)
+    B, C, H = 2, 32, 16
+    x = nets.analytic_input((B, C, H, H), seed=1) - 0.5
+    flo = (nets.analytic_input((B, 2, H, H), seed=2) - 0.5) * 3
+    g = nets.analytic_input((B, C, H, H), seed=3) - 0.5
+    a, f = x.clone().requires_grad_(), flo.clone().requires_grad_()
+    (oops.pwc_warp(a, f * 1.25) * g).sum().backward()
+    xv, gv = ws.new(B, H, H, C), ws.new(B, H, H, C)
+    xv.buf[...] = x.permute(0, 2, 3, 1).to(DEV); gv.buf[...] = g.permute(0, 2, 3, 1).to(DEV)
+    fv = ws.new(B, H, H, 2, dtype=torch.float32, pad=2); fv.buf[...] = flo.permute(0, 2, 3, 1).to(DEV)
+    dx = ws.new(B, H, H, C, dtype=torch.float32); df = ws.new(B, H, H, 2, dtype=torch.float32, pad=2)
+    _lib.call("mireg_pwc_warp_bwd", xv.ptr, xv.ld, fv.ptr, fv.ld, 1.25, gv.ptr, gv.ld, dx.ptr, dx.ld, df.ptr, df.ld, B, H, H, C,
+              ws.code, _stream())
+    assert _rel(dx.nchw(), a.grad) < 1e-5
+    assert _rel(df.nchw(), f.grad) < 1e-4
+
+
+def test_pwcnet_training_gradients_match_oracle():
+    """PWC-DC-Net fp32: gradients through dense estimators, cost volumes, warps, context net and the siamese pyramid."""
+    import mireg
+    torch.manual_seed(0)
+    m = mireg.PWCDCNet(md=4, precision="fp32")
+    nets.analytic_weights_(m)
+    o = nets.PWCDCNet(md=4)
+    o.load_state_dict(m.state_dict())
+    m = m.to(DEV).train(); o.train()
+    x = nets.analytic_input((2, 2, 128, 128), seed=9)
+
+    def objective(fl, dev):
+        return sum((f * torch.cos(torch.arange(f.numel(), dtype=torch.float32).reshape(f.shape) * 0.01).to(dev)).sum() for f in fl)
+    objective(o(x), "cpu").backward()
+    objective(m(x.to(DEV)), DEV).backward()
+    P, Q = dict(m.named_parameters()), dict(o.named_parameters())
+    worst = ("", 0.0)
+    for k in ("conv1a.0.weight", "conv1a.0.bias", "conv2b.0.weight", "conv4aa.0.weight", "conv6b.0.weight", "conv6_0.0.weight",
+              "conv6_4.0.bias", "conv5_2.0.weight", "conv3_0.0.weight", "conv2_4.0.weight", "predict_flow6.weight",
+              "predict_flow2.bias", "deconv6.weight", "deconv3.bias", "upfeat5.weight", "upfeat3.bias", "dc_conv1.0.weight",
+              "dc_conv4.0.weight", "dc_conv7.weight", "deconv2.weight", "deconv1.weight", "deconv1.bias"):
+        a, b = P[k].grad.detach().cpu().double(), Q[k].grad.double()
+        rel = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        if rel > worst[1]:
+            worst = (k, rel)
+        assert rel < 2e-2, (k, rel)
+    print("worst relative L2 gradient error", worst)
