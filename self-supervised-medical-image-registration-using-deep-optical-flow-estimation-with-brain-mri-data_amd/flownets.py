@@ -83,12 +83,33 @@ class PredictorEngineBase:
         _lib.call("mireg_pack_weights", self._pack_table.data_ptr(), self._pack_n, self._pack_units, self._pack_dunits,
                   self.ws.code, _stream())
 
-    def unpack_grads(self) -> None:
+    def unpack_grads(self, names: Optional[Sequence[str]] = None) -> None:
+        """wgrad slabs -> torch-layout gradients, for all layers or for the named subset (one backward phase)."""
+        key = tuple(names) if names is not None else None
         if self._unpack_table is None:
-            jobs = [l.unpack_job() for l in self.layers.values() if l.wgrad_slab is not None]
-            self._unpack_units, _ = assign_tiles(jobs, True)
-            self._unpack_table, self._unpack_n = upload_table(jobs, self.ws.device), len(jobs)
-        _lib.call("mireg_unpack_wgrad", self._unpack_table.data_ptr(), self._unpack_n, self._unpack_units, _stream())
+            self._unpack_table = {}
+        if key not in self._unpack_table:
+            layers = [self.layers[n] for n in names] if names is not None else list(self.layers.values())
+            jobs = [l.unpack_job() for l in layers if l.wgrad_slab is not None]
+            units, _ = assign_tiles(jobs, True)
+            self._unpack_table[key] = (upload_table(jobs, self.ws.device), len(jobs), units)
+        tab, n, units = self._unpack_table[key]
+        _lib.call("mireg_unpack_wgrad", tab.data_ptr(), n, units, _stream())
+
+    def flat_range(self, layer_names: Sequence[str], bn_names: Sequence[str] = ()) -> Tuple[int, int]:
+        """[start, end) of the flat gradient buffer covered by these layers' parameters (must be contiguous)."""
+        ps = []
+        for n in layer_names:
+            l = self.layers[n]
+            ps.append(l.weight)
+            if l.bias is not None:
+                ps.append(l.bias)
+        for n in bn_names:
+            ps += [self.bns[n].bn.weight, self.bns[n].bn.bias]
+        lo = min(self.flat_off[id(p)] for p in ps)
+        hi = max(self.flat_off[id(p)] + p.numel() for p in ps)
+        assert hi - lo == sum(p.numel() for p in {id(p): p for p in ps}.values()), "phase parameters are not contiguous"
+        return lo, hi
 
     def bind_flat_grads(self, params: Sequence[nn.Parameter], flat: torch.Tensor) -> None:
         """Make every gradient buffer a view of `flat` (parameter order), so one RCCL all-reduce / one Adam
@@ -98,6 +119,7 @@ class PredictorEngineBase:
             off[id(p)] = o
             o += p.numel()
         assert o == flat.numel()
+        self.flat_off = off
 
         def view(p):
             return flat[off[id(p)]:off[id(p)] + p.numel()].view(p.shape)
@@ -304,17 +326,41 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
             "conv6": (dc[5].slice(0, 512), True, self.da6), "conv6_1": (self.da6, False, self.da61)}
         self.grads_ready = True
 
-    def backward(self, gflows: Sequence[Optional[torch.Tensor]]) -> None:
-        """gflows: gradients wrt (flow0, flow2, flow3, flow4, flow5, flow6) as (B,2,h,w) fp32 or None."""
+    DEC_LAYERS = [f"deconv{l}" for l in DECONV] + [f"predict_flow{l}" for l in PREDICT] + [f"up{l}" for l in (6, 5, 4, 3)]
+    PHASE_ENC = (("conv6_1", "conv6", "conv5_1", "conv5"), ("conv4_1", "conv4", "conv3_1", "conv3", "conv2", "conv1"))
+
+    def backward_phases(self, gflows: Sequence[Optional[torch.Tensor]]):
+        """The backward pass cut where gradient buckets complete: decoder | conv6_1..conv5 | conv4_1..conv1.
+        In parameter order these are the tail, the middle and the head of the flat gradient buffer, so the trainer
+        can start the all-reduce of a finished bucket while the next phase computes."""
         self._ensure_grad_buffers()
         g = list(gflows) + [None] * (6 - len(gflows))
-        self.decoder_backward({2: g[1], 3: g[2], 4: g[3], 5: g[4], 6: g[5]}, g[0])
-        for name, *_ in reversed(ENCODER):                                    # encoder, coarse -> fine
-            src, dst = self.enc_io[name]
-            dsrc, acc, ddst = self.enc_dio[name]
-            self.chain_backward(name, src, dst, dsrc, acc, ddst)
-        self.join_side()
-        self.unpack_grads()
+
+        def decoder():
+            self.decoder_backward({2: g[1], 3: g[2], 4: g[3], 5: g[4], 6: g[5]}, g[0])
+            self.join_side()
+            self.unpack_grads(self.DEC_LAYERS)
+
+        def encoder(names):
+            def run():
+                for name in names:
+                    src, dst = self.enc_io[name]
+                    dsrc, acc, ddst = self.enc_dio[name]
+                    self.chain_backward(name, src, dst, dsrc, acc, ddst)
+                self.join_side()
+                self.unpack_grads(names)
+            return run
+        return [decoder, encoder(self.PHASE_ENC[0]), encoder(self.PHASE_ENC[1])]
+
+    def phase_ranges(self) -> List[Tuple[int, int]]:
+        bn = lambda names: names if self.bn else ()
+        return [self.flat_range(self.DEC_LAYERS), self.flat_range(self.PHASE_ENC[0], bn(self.PHASE_ENC[0])),
+                self.flat_range(self.PHASE_ENC[1], bn(self.PHASE_ENC[1]))]
+
+    def backward(self, gflows: Sequence[Optional[torch.Tensor]]) -> None:
+        """gflows: gradients wrt (flow0, flow2, flow3, flow4, flow5, flow6) as (B,2,h,w) fp32 or None."""
+        for phase in self.backward_phases(gflows):
+            phase()
 
 
 class _FlowNetSFn(torch.autograd.Function):

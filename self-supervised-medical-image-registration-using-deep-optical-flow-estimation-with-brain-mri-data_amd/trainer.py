@@ -113,7 +113,7 @@ class RegistrationTrainer:
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-4,
                  lamb_da: float = 0.5, gamma: float = 100.0, zeta: float = 100.0, use_graph: bool = True,
-                 process_group=None, sync_loss_stats: bool = False):
+                 process_group=None, sync_loss_stats: bool = False, overlap: bool = True):
         self.model = model
         self.predictor = model.predictor
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -124,6 +124,9 @@ class RegistrationTrainer:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self.sync_loss_stats = sync_loss_stats and self.world > 1
+        self.overlap = overlap
+        self._graphs = None
+        self._seg_ranges = [None]
         self.flat_p = flatten_parameters(model)
         dev = self.flat_p.device
         self.flat_g = torch.zeros_like(self.flat_p)
@@ -150,19 +153,48 @@ class RegistrationTrainer:
         B, _, H, W = x.shape
         self.loss = FusedRegLoss(B, H, W, sizes, x.device, *self.loss_hyper)
 
-    def _fwd_bwd(self) -> None:
+    def _forward_and_loss(self):
         flows = self.eng.forward(self.x_static, True)
         self.loss.forward(self.x_static, flows)
         Bg = self.loss.B * self.world if self.sync_loss_stats else None
         if self.sync_loss_stats:
             mdist.all_reduce_loss_moments_(self.loss.sums, self.pg)
         self.loss.finalize(Bg)
-        gflows = self.loss.backward(flows, Bg)
-        self.eng.backward(gflows)
+        return self.loss.backward(flows, Bg)
+
+    def _fwd_bwd(self) -> None:
+        self.eng.backward(self._forward_and_loss())
+
+    def _segments(self):
+        """[(callable, flat-gradient range or None)]: the step cut where gradient buckets complete (DP overlap)."""
+        if self.world > 1 and self.overlap and hasattr(self.eng, "backward_phases"):
+            holder = {}
+
+            def first():
+                holder["phases"] = self.eng.backward_phases(self._forward_and_loss())
+                holder["phases"][0]()
+            ranges = self.eng.phase_ranges()
+            segs = [(first, ranges[0])]
+            for k in range(1, len(ranges)):
+                segs.append(((lambda k=k: holder["phases"][k]()), ranges[k]))
+            return segs
+        return [(self._fwd_bwd, None)]
 
     def _optim(self) -> None:
         _lib.call("mireg_adam_step", self._adam_tab.data_ptr(), 1, self.step_dev.data_ptr(), self.lr, self.betas[0],
                   self.betas[1], self.eps, 1.0 / self.world, _stream())
+
+    def _run(self, runners) -> None:
+        """runners[i]() executes segment i (eagerly or as a hipGraph replay); finished buckets are all-reduced
+        asynchronously (RCCL runs on its own stream) while the next segment computes."""
+        works = []
+        for run, rng in zip(runners, self._seg_ranges):
+            run()
+            if self.world > 1:
+                buf = self.flat_g if rng is None else self.flat_g[rng[0]:rng[1]]
+                works.append(torch.distributed.all_reduce(buf, group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
 
     def step(self, x: torch.Tensor) -> torch.Tensor:
         """One optimizer step on batch x (B,2,H,W) fp32 on device.  Returns the device tensor
@@ -172,14 +204,14 @@ class RegistrationTrainer:
         self.x_static.copy_(x)
         graphable = self.use_graph and not self.sync_loss_stats
         if graphable and self._warm >= 2:
-            if self._graph_fb is None:
+            if self._graphs is None:
                 self._capture()
-            self._graph_fb.replay()
-            mdist.all_reduce_gradients_(self.flat_g, self.pg)
+            self._run([g.replay for g in self._graphs])
             self._graph_opt.replay()
         else:
-            self._fwd_bwd()
-            mdist.all_reduce_gradients_(self.flat_g, self.pg)
+            segs = self._segments()
+            self._seg_ranges = [r for _, r in segs]
+            self._run([f for f, _ in segs])
             self._optim()
             self._warm += 1
         return self.loss.out4
@@ -188,14 +220,20 @@ class RegistrationTrainer:
         torch.cuda.synchronize()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        segs = self._segments()
+        self._seg_ranges = [r for _, r in segs]
+        self._graphs = []
         with torch.cuda.stream(s):
-            self._graph_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_fb, stream=s):
-                self._fwd_bwd()
+            for fn, _ in segs:
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=s):
+                    fn()
+                self._graphs.append(gr)
             self._graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_opt, stream=s):
                 self._optim()
         torch.cuda.current_stream().wait_stream(s)
+        self._graph_fb = self._graphs[0]
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
