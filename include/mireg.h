@@ -75,6 +75,11 @@ int mireg_ofe_finalize(const double* sums, const long* npix, int n, int B, doubl
 int mireg_ofe_bwd_coef(const double* sums, const long* npix, int n, int B, double lamb_da, double gamma,
                        double zeta, const double* g4, float* coef, hipStream_t stream);
 
+/* ---- K19: F.grid_sample(vol, F.affine_grid(theta, vol.size())), models.py:187-188 (trilinear, zeros,
+ * align_corners=False); planar (B,C,D,H,W) fp32 volumes, theta (B,3,4) ---------------------------------- */
+int mireg_affine_sample3d(const float* vol, const float* theta, float* out, int B, int C, int D, int H, int W,
+                          hipStream_t stream);
+
 /* ---- K14/K15: models.py:286 (rint + clip 0..3, on device), utils.py:72-91 (Dice) --------- */
 int mireg_seg_round(const float* in, float* out, long n, hipStream_t stream);
 /* counts: workspace B*9 floats; dice[b] = mean_l 2|A_l & B_l| / (|A_l| + |B_l|), l = 1..3 */
@@ -119,6 +124,10 @@ typedef struct mireg_conv_desc {
                               sub-grid, output offset and weights per parity class), everything else is shared */
   mireg_conv_cls cls[4];
   long slab_cls_stride;    /* floats between the split-K slabs of consecutive classes */
+  /* optional depth axis for Conv3d (reference models.py:39-43,160-165), NDHWC volumes; all zero for 2-D launches:
+   * iz = gz*mul_z + off_z + tz*step_z in [0, x_D); rows run over (n_img, g_D, g_H, g_W); k = ((tz*taps_y+ty)*taps_x+tx)*x_C + c;
+   * output voxel z = gz*y_mul_z + y_off_z in a y_D deep volume.  mireg_conv_gemm only (single class). */
+  int x_D, taps_z, mul_z, off_z, step_z, g_D, y_D, y_mul_z, y_off_z;
 } mireg_conv_desc;
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream);
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);

@@ -11,7 +11,8 @@ from .flownets import FlowNetS  # noqa: F401
 from .flownetc import FlowNetC  # noqa: F401
 from .pwcnet import PWCDCNet  # noqa: F401
 from .correlation import Correlation  # noqa: F401
+from .affine3d import Affloss, affmodel  # noqa: F401
 from .models import generate_grid, grid_generator, opticalFlowReg  # noqa: F401
 from .trainer import RegistrationTrainer  # noqa: F401
 
-__all__ = ["FlowNetS", "FlowNetC", "PWCDCNet", "Correlation", "opticalFlowReg", "RegistrationTrainer", "generate_grid", "grid_generator", "OFEloss", "dice_average", "dice_batch", "resize_bilinear", "seg_round", "stn"]
+__all__ = ["affmodel", "Affloss", "FlowNetS", "FlowNetC", "PWCDCNet", "Correlation", "opticalFlowReg", "RegistrationTrainer", "generate_grid", "grid_generator", "OFEloss", "dice_average", "dice_batch", "resize_bilinear", "seg_round", "stn"]

@@ -113,8 +113,10 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
   const int wm = wid / WN, wn = wid % WN;
   const int r = lane & 31, h = lane >> 5;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int gHW = p.g_H * p.g_W;
-  const int M = p.n_img * gHW;
+  // optional depth axis (Conv3d): all *_D / *_z fields are 0 for 2-D launches and then collapse to extent 1
+  const int xD = max(p.x_D, 1), gD = max(p.g_D, 1), tapsZ = max(p.taps_z, 1), yD = max(p.y_D, 1), ymz = max(p.y_mul_z, 1);
+  const int gHW = p.g_H * p.g_W, gDHW = gD * gHW;
+  const int M = p.n_img * gDHW;
   const int my_tiles = ((M + BM - 1) / BM) * tiles_n;
   // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so give each XCD a contiguous
   // run of tiles (neighbouring m-tiles x all n-tiles): its 4 MiB L2 then holds that run's pixels and the weights.
@@ -126,7 +128,7 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
   if (bid >= my_tiles) return;                                      // classes with fewer tiles than the grid
   const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int K = p.taps_y * p.taps_x * p.x_C;
+  const int K = tapsZ * p.taps_y * p.taps_x * p.x_C;
   const int nk_total = (K + BK - 1) / BK;
   int kt_begin = 0, kt_end = nk_total;
   if (p.split_k > 1) {
@@ -141,15 +143,17 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
   const int lrow = lane >> 2;
   const int kc = (lane & 3) ^ ((lane >> 4) & 3);                   // logical 16-B chunk of the K-step this lane fetches
   unsigned a_base[A_PW];                                            // byte offset of the image, or OOB
-  int a_iy0[A_PW], a_ix0[A_PW];
+  int a_iz0[A_PW], a_iy0[A_PW], a_ix0[A_PW];
 #pragma unroll
   for (int c = 0; c < A_PW; ++c) {
     const int m = m0 + (wid + 4 * c) * 16 + lrow;
     const bool ok = m < M;
     const int mm = ok ? m : 0;
-    const int img = mm / gHW, rem = mm - img * gHW;
+    const int img = mm / gDHW, r3 = mm - img * gDHW;
+    const int gz = r3 / gHW, rem = r3 - gz * gHW;
     const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
-    a_base[c] = ok ? (unsigned)((long)img * p.x_H * p.x_W * p.x_ld * (long)sizeof(T)) : kOOB;
+    a_base[c] = ok ? (unsigned)((long)img * xD * p.x_H * p.x_W * p.x_ld * (long)sizeof(T)) : kOOB;
+    a_iz0[c] = gz * p.mul_z + p.off_z;
     a_iy0[c] = gy * p.mul_y + p.off_y;
     a_ix0[c] = gx * p.mul_x + p.off_x;
   }
@@ -161,13 +165,16 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
     b_base[c] = (g < B_GROUPS && n < p.N) ? (unsigned)((long)n * p.w_ld * (long)sizeof(T)) : kOOB;
   }
   const int cpt = p.x_C / CPC;
-  int ty, tx, cc;
+  int tz, ty, tx, cc;
   {
     const int q = kt_begin * 4 + kc;
     const int tap = q / cpt;
     cc = q - tap * cpt;
-    ty = tap / p.taps_x;
-    tx = tap - ty * p.taps_x;
+    const int tyx = p.taps_y * p.taps_x;
+    tz = tap / tyx;
+    const int t2 = tap - tz * tyx;
+    ty = t2 / p.taps_x;
+    tx = t2 - ty * p.taps_x;
   }
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
@@ -175,12 +182,13 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
   // lane's chunk walks into the next tap, so the steady-state K-step costs a handful of VALU ops per DMA
   unsigned a_cur[A_PW];
   auto set_tap = [&]() {
-    const bool kvalid = ty < p.taps_y;
+    const bool kvalid = tz < tapsZ;
 #pragma unroll
     for (int c = 0; c < A_PW; ++c) {
-      const int iy = a_iy0[c] + ty * p.step_y, ix = a_ix0[c] + tx * p.step_x;
-      const bool ok = kvalid && a_base[c] != kOOB && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
-      a_cur[c] = ok ? a_base[c] + (unsigned)((((long)iy * p.x_W + ix) * p.x_ld) * (long)sizeof(T)) : kOOB;
+      const int iz = a_iz0[c] + tz * p.step_z, iy = a_iy0[c] + ty * p.step_y, ix = a_ix0[c] + tx * p.step_x;
+      const bool ok = kvalid && a_base[c] != kOOB && (unsigned)iz < (unsigned)xD && (unsigned)iy < (unsigned)p.x_H &&
+                      (unsigned)ix < (unsigned)p.x_W;
+      a_cur[c] = ok ? a_base[c] + (unsigned)(((((long)iz * p.x_H + iy) * p.x_W + ix) * p.x_ld) * (long)sizeof(T)) : kOOB;
     }
   };
   set_tap();
@@ -206,7 +214,7 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
     b_k += BK * (int)sizeof(T);
     cc += 4;
     if (cc >= cpt) {
-      do { cc -= cpt; if (++tx == p.taps_x) { tx = 0; ++ty; } } while (cc >= cpt);
+      do { cc -= cpt; if (++tx == p.taps_x) { tx = 0; if (++ty == p.taps_y) { ty = 0; ++tz; } } } while (cc >= cpt);
       set_tap();
     }
   };
@@ -322,9 +330,10 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
     if (m < M) {
       if (slab_out) off = ((long)blockIdx.z * M + m) * p.N;
       else {
-        const int img = m / gHW, rem = m - img * gHW;
+        const int img = m / gDHW, r3 = m - img * gDHW;
+        const int gz = r3 / gHW, rem = r3 - gz * gHW;
         const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
-        off = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
+        off = (((long)img * yD + gz * ymz + p.y_off_z) * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
       }
     }
     rowoff[tid] = off;
@@ -407,8 +416,15 @@ splitk_reduce_kernel(const mireg_conv_desc pd) {
     p.g_H = k.g_H; p.g_W = k.g_W; p.y_off_y = k.y_off_y; p.y_off_x = k.y_off_x;
   }
   const float* __restrict__ slab = p.slab + (long)blockIdx.y * pd.slab_cls_stride;
-  const int gHW = p.g_H * p.g_W;
-  const long M = (long)p.n_img * gHW, total = M * p.N;
+  const int gD = max(p.g_D, 1), yD = max(p.y_D, 1), ymz = max(p.y_mul_z, 1);
+  const int gHW = p.g_H * p.g_W, gDHW = gD * gHW;
+  const long M = (long)p.n_img * gDHW, total = M * p.N;
+  auto out_pix = [&](long m) -> long {
+    const int img = (int)(m / gDHW), r3 = (int)(m - (long)img * gDHW);
+    const int gz = r3 / gHW, rem = r3 - gz * gHW;
+    const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
+    return (((long)img * yD + gz * ymz + p.y_off_z) * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
+  };
   T* __restrict__ yp = reinterpret_cast<T*>(p.y);
   const bool vec = (p.N % 4) == 0 && yp && (p.y_ld % 4) == 0 && !p.y32;
   if (vec) {                                                        // 4 channels per thread: 16-B slab reads
@@ -422,9 +438,7 @@ splitk_reduce_kernel(const mireg_conv_desc pd) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += __uint_as_float(c.w[q]);
       }
-      const int img = (int)(m / gHW), rem = (int)(m - (long)img * gHW);
-      const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
-      const long pix = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
+      const long pix = out_pix(m);
       T* d = yp + pix * p.y_ld + n;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -444,9 +458,7 @@ splitk_reduce_kernel(const mireg_conv_desc pd) {
     for (int z = 0; z < p.split_k; ++z) v += slab[(long)z * total + i];
     if (p.bias) v += p.bias[n];
     v = v > 0.f ? v : v * p.slope;
-    const int img = (int)(m / gHW), rem = (int)(m - (long)img * gHW);
-    const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
-    const long pix = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
+    const long pix = out_pix(m);
     if (yp) {
       T* d = yp + pix * p.y_ld + n;
       if (p.accumulate & 1) v += to_f32(*d);
@@ -838,7 +850,7 @@ int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
   const int ncls = p.n_cls > 1 ? p.n_cls : 1;
   long M = 0;                                                       // largest class decides the grid
   for (int c = 0; c < ncls; ++c) {
-    const long m = ncls > 1 ? (long)p.n_img * p.cls[c].g_H * p.cls[c].g_W : (long)p.n_img * p.g_H * p.g_W;
+    const long m = (ncls > 1 ? (long)p.n_img * p.cls[c].g_H * p.cls[c].g_W : (long)p.n_img * p.g_H * p.g_W) * (p.g_D > 0 ? p.g_D : 1);
     M = m > M ? m : M;
   }
   const int z = p.split_k > 1 ? p.split_k : 1;
@@ -881,7 +893,8 @@ bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
   const int cpc = p->dtype == MIREG_DTYPE_BF16 ? 8 : 4;
   if (p->dtype != MIREG_DTYPE_BF16 && p->dtype != MIREG_DTYPE_F32) return false;
   if (p->x_C <= 0 || p->x_C % cpc || p->x_ld % cpc || ((uintptr_t)p->x % 16)) return false;
-  if ((long)p->n_img * p->g_H * p->g_W >= (1L << 31)) return false;
+  if ((long)p->n_img * p->g_H * p->g_W * (p->g_D > 0 ? p->g_D : 1) >= (1L << 31)) return false;
+  if (wgrad && (p->g_D > 1 || p->taps_z > 1)) return false;                 // Conv3d backward-weights: not yet
   if (wgrad) {
     if (!p->y || !p->slab || p->y_ld % cpc || ((uintptr_t)p->y % 16)) return false;
   } else {

@@ -416,6 +416,41 @@ __global__ void dice_finalize_kernel(const float* __restrict__ counts, float* __
   dice[b] = m / 3.f;
 }
 
+// F.grid_sample(vol, F.affine_grid(theta, vol.size())) with both torch defaults (align_corners=False, trilinear,
+// zeros) for planar volumes (B,C,D,H,W): reference models.py:187-188 (affmodel).  theta: (B,3,4) row-major.
+__global__ void __launch_bounds__(kThreads)
+affine_sample3d_kernel(const float* __restrict__ vol, const float* __restrict__ theta, float* __restrict__ out,
+                       int B, int C, int D, int H, int W) {
+  const long nvox = (long)D * H * W, total = (long)B * nvox;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / nvox);
+    const long v = i - (long)b * nvox;
+    const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((long)W * H));
+    const float* t = theta + b * 12;
+    // affine_grid base coordinates (align_corners=False): (2i + 1)/n - 1
+    const float bx = (2.f * x + 1.f) / (float)W - 1.f, by = (2.f * y + 1.f) / (float)H - 1.f, bz = (2.f * z + 1.f) / (float)D - 1.f;
+    const float gx = t[0] * bx + t[1] * by + t[2] * bz + t[3];
+    const float gy = t[4] * bx + t[5] * by + t[6] * bz + t[7];
+    const float gz = t[8] * bx + t[9] * by + t[10] * bz + t[11];
+    const float px = ((gx + 1.f) * (float)W - 1.f) / 2.f, py = ((gy + 1.f) * (float)H - 1.f) / 2.f, pz = ((gz + 1.f) * (float)D - 1.f) / 2.f;
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx1 = px - fx, wy1 = py - fy, wz1 = pz - fz;
+    for (int c = 0; c < C; ++c) {
+      const float* src = vol + ((long)b * C + c) * nvox;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int xi = x0 + (k & 1), yi = y0 + ((k >> 1) & 1), zi = z0 + (k >> 2);
+        if (xi < 0 || xi >= W || yi < 0 || yi >= H || zi < 0 || zi >= D) continue;
+        const float wgt = ((k & 1) ? wx1 : 1.f - wx1) * (((k >> 1) & 1) ? wy1 : 1.f - wy1) * ((k >> 2) ? wz1 : 1.f - wz1);
+        acc += src[((long)zi * H + yi) * W + xi] * wgt;
+      }
+      out[((long)b * C + c) * nvox + v] = acc;
+    }
+  }
+}
+
 inline int grid_for(long work, int cap = 2048) {
   long g = (work + kThreads - 1) / kThreads;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -517,6 +552,13 @@ int mireg_ofe_bwd_coef(const double* sums, const long* npix, int n, int B, doubl
                        const double* g4, float* coef, hipStream_t stream) {
   MIREG_CHECK_ARG(sums && npix && g4 && coef && n > 0 && n <= 16 && B > 0);
   hipLaunchKernelGGL(ofe_bwd_coef_kernel, dim3(1), dim3(64), 0, stream, sums, npix, n, B, lamb_da, gamma, zeta, g4, coef);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_affine_sample3d(const float* vol, const float* theta, float* out, int B, int C, int D, int H, int W,
+                          hipStream_t stream) {
+  MIREG_CHECK_ARG(vol && theta && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
+  hipLaunchKernelGGL(affine_sample3d_kernel, dim3(grid_for((long)B * D * H * W)), dim3(kThreads), 0, stream, vol, theta, out, B, C, D, H, W);
   MIREG_LAUNCH_RET();
 }
 

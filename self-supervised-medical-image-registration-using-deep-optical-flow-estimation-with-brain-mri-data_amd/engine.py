@@ -46,7 +46,10 @@ class ConvDesc(ctypes.Structure):
                 ("y32", ctypes.c_void_p), ("y32_ld", ctypes.c_long),
                 ("bias", ctypes.c_void_p), ("slope", ctypes.c_float), ("accumulate", ctypes.c_int), ("dtype", ctypes.c_int),
                 ("split_k", ctypes.c_int), ("slab", ctypes.c_void_p), ("x_bytes", ctypes.c_long), ("w_bytes", ctypes.c_long),
-                ("n_cls", ctypes.c_int), ("cls", ConvCls * 4), ("slab_cls_stride", ctypes.c_long)]
+                ("n_cls", ctypes.c_int), ("cls", ConvCls * 4), ("slab_cls_stride", ctypes.c_long),
+                ("x_D", ctypes.c_int), ("taps_z", ctypes.c_int), ("mul_z", ctypes.c_int), ("off_z", ctypes.c_int),
+                ("step_z", ctypes.c_int), ("g_D", ctypes.c_int), ("y_D", ctypes.c_int), ("y_mul_z", ctypes.c_int),
+                ("y_off_z", ctypes.c_int)]
 
 
 class PackClass(ctypes.Structure):
