@@ -156,6 +156,26 @@ int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int total_unit
                        hipStream_t stream);
 int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, int total_units, hipStream_t stream);
 
+/* ---- packed-domain optimizer for the convolution weights (train.py:55-57,129 zero_grad/backward/step) ----
+ * The torch-layout gradient is never materialised on the training path:
+ *   mireg_wgrad_reduce : g[co][k] = sum_{z<nsplit} slab[z][co][k]       (fixed order; jobs with nsplit == 0 own no units)
+ *   mireg_adam_pack    : torch.optim.Adam step on p/m/v (torch layout [Co][Ci][taps], fp32) with the gradient read
+ *                        from the packed g[co][tap*Cpad+ci], then F[co][tap*Cpad+ci] = (dtype)p (pad slots zero).
+ * g of every layer lives in one flat buffer, so under data parallelism it is what RCCL all-reduces. */
+typedef struct mireg_wopt_job {
+  const float* slab; long slab_stride; int nsplit;
+  float* g;
+  float* p; float* m; float* v;
+  void* F;
+  int Co, Ci, taps, Cpad; long ld;
+  int runit0;     /* first reduce block: blocks = ceil(Co*ld / 256), 0 blocks when nsplit == 0 */
+  int unit0;      /* first optimizer block: blocks = Co * ceil(Cpad/64) */
+} mireg_wopt_job;
+int mireg_wgrad_reduce(const mireg_wopt_job* jobs_dev, int njobs, int total_runits, hipStream_t stream);
+/* max_taps = largest kh*kw in the table (<= 49); tick != 0 increments *step_dev first (as mireg_adam_step does) */
+int mireg_adam_pack(const mireg_wopt_job* jobs_dev, int njobs, int total_units, int max_taps, int* step_dev, int tick,
+                    float lr, float beta1, float beta2, float eps, float grad_scale, int dtype, hipStream_t stream);
+
 /* ---- K1 tail: BatchNorm2d (batch statistics in train mode) + LeakyReLU, FlowNetS/util.py:17-30 ---- */
 /* y = raw convolution output [M][ld_y]; out = lrelu(bn(y)); ss = [scale | shift | mean | rstd] (4*C floats,
  * kept for the backward pass); partial = workspace of MIREG_BN_MAX_BLOCKS * 2 * C floats (two-stage,

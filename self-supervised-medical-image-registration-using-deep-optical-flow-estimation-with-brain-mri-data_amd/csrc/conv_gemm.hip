@@ -281,13 +281,12 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
   int it = 0;
   const int steady = nk - (STAGES - 1);
   if (loads_per_tile == A_PW + B_PW) {                               // every wave of 128/64-wide tiles: immediate count
-    const bool no_issue = p.accumulate & 4, no_compute = p.accumulate & 2;   // ABLATION ONLY
     for (; it < steady; ++it) {
       wait_vmcnt<2 * (A_PW + B_PW)>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (!no_issue) issue((it + STAGES - 1) % STAGES);
-      if (!no_compute) compute(it % STAGES);
+      issue((it + STAGES - 1) % STAGES);
+      compute(it % STAGES);
     }
   } else {
     for (; it < steady; ++it) {

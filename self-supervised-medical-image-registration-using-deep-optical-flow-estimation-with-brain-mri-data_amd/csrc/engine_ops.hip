@@ -429,6 +429,86 @@ adam_kernel(const mireg_adam_job* __restrict__ jobs, const int* __restrict__ ste
   }
 }
 
+
+// ==============================================================================================
+// packed-domain optimizer: split-K wgrad slabs -> packed gradient -> Adam on the torch-layout master
+// weights -> refreshed FWD pack, without ever materialising the torch-layout gradient.
+// ==============================================================================================
+__device__ __forceinline__ int find_wopt(const mireg_wopt_job* jobs, int njobs, int unit, bool reduce) {
+  int lo = 0;
+  for (int i = 1; i < njobs; ++i) {
+    const mireg_wopt_job* j = GPTR(const mireg_wopt_job, jobs + i);
+    if ((reduce ? j->runit0 : j->unit0) <= unit) lo = i;
+  }
+  return lo;
+}
+
+// g[e] = sum_z slab[z][e]; block = 256 consecutive floats (64 float4 lanes) x 4 z-groups, fixed summation order
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const mireg_wopt_job* __restrict__ jobs, int njobs) {
+  __shared__ float4 part[3][64];
+  const mireg_wopt_job j = *GPTR(const mireg_wopt_job, jobs + find_wopt(jobs, njobs, blockIdx.x, true));
+  const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  const long E = (long)j.Co * j.ld, e = ((long)(blockIdx.x - j.runit0) * 64 + lane) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < E) {
+    const float* sp = j.slab + e;
+#pragma unroll 4
+    for (int z = zg; z < j.nsplit; z += 4) {
+      const float4 q = *GPTR(const float4, sp + (long)z * j.slab_stride);
+      acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+    }
+  }
+  if (zg) part[zg - 1][lane] = acc;
+  __syncthreads();
+  if (zg == 0 && e < E) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float4 q = part[k][lane]; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+    *GPTR(float4, j.g + e) = acc;
+  }
+}
+
+constexpr int kOptMaxTaps = 49;
+// block = one (co, 64-ci chunk): packed gradient -> LDS (transposed) -> coalesced torch-order Adam -> FWD pack row
+template <typename T>
+__global__ void __launch_bounds__(256)
+adam_pack_kernel(const mireg_wopt_job* __restrict__ jobs, int njobs, const int* __restrict__ step, float lr, float b1, float b2,
+                 float eps, float grad_scale) {
+  __shared__ float tile[64 * kOptMaxTaps];
+  const mireg_wopt_job j = *GPTR(const mireg_wopt_job, jobs + find_wopt(jobs, njobs, blockIdx.x, false));
+  const int taps = j.taps, tp = taps | 1, tid = threadIdx.x;
+  const int chunks = (j.Cpad + 63) / 64;
+  const int u = blockIdx.x - j.unit0;
+  const int co = u / chunks, ci0 = (u - co * chunks) * 64;
+  const int nci = max(0, min(64, j.Ci - ci0));
+  const int run = nci * taps;
+  const float t = (float)*step;
+  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  const float step_size = lr / bc1;
+  const float* g = j.g + (long)co * j.ld + ci0;
+  for (int e = tid; e < taps * 64; e += 256) {
+    const int tap = e >> 6, ci = e & 63;
+    if (ci < nci) tile[ci * tp + tap] = ldf(g + (long)tap * j.Cpad + ci);
+  }
+  __syncthreads();
+  const unsigned magic = (unsigned)((0x100000000ull + taps - 1) / taps);
+  const long base = ((long)co * j.Ci + ci0) * taps;
+  for (int r = tid; r < run; r += 256) {
+    const int ci = (int)__umulhi((unsigned)r, magic), idx = ci * tp + (r - ci * taps);
+    const float gg = tile[idx] * grad_scale;
+    const float m = b1 * ldf(j.m + base + r) + (1.f - b1) * gg;
+    const float v = b2 * ldf(j.v + base + r) + (1.f - b2) * gg * gg;
+    const float pn = ldf(j.p + base + r) - step_size * (m / (sqrtf(v) / bc2s + eps));
+    stf(j.m + base + r, m); stf(j.v + base + r, v); stf(j.p + base + r, pn);
+    tile[idx] = pn;
+  }
+  __syncthreads();
+  T* F = reinterpret_cast<T*>(j.F) + (long)co * j.ld + ci0;
+  for (int e = tid; e < taps * 64; e += 256) {
+    const int tap = e >> 6, ci = e & 63;
+    if (ci0 + ci < j.Cpad) stf(F + (long)tap * j.Cpad + ci, ci < nci ? tile[ci * tp + tap] : 0.f);
+  }
+}
+
 inline int grid1(long work, int cap = 4096) {
   long g = (work + 255) / 256;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -469,14 +549,14 @@ extern "C" {
 
 int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int total_units, int total_dgrad_units, int dtype,
                        hipStream_t stream) {
-  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units > 0 && total_dgrad_units >= 0 &&
-                  (dtype == MIREG_DTYPE_F32 || dtype == MIREG_DTYPE_BF16));
-  const int g = total_units / 4 + 1 < 2048 ? total_units / 4 + 1 : 2048;
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units >= 0 && total_dgrad_units >= 0 &&
+                  total_units + total_dgrad_units > 0 && (dtype == MIREG_DTYPE_F32 || dtype == MIREG_DTYPE_BF16));
+  const int g = total_units / 4 + 1 < 2048 ? total_units / 4 + 1 : 2048;     // total_units == 0: DGRAD packs only (FWD packs are fresh)
   if (dtype == MIREG_DTYPE_BF16) {
-    hipLaunchKernelGGL((pack_fwd_kernel<__bf16, 0>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
+    if (total_units) hipLaunchKernelGGL((pack_fwd_kernel<__bf16, 0>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
     if (total_dgrad_units) hipLaunchKernelGGL((pack_dgrad_kernel<__bf16>), dim3(total_dgrad_units), dim3(256), 0, stream, jobs_dev, njobs);
   } else {
-    hipLaunchKernelGGL((pack_fwd_kernel<float, 0>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
+    if (total_units) hipLaunchKernelGGL((pack_fwd_kernel<float, 0>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
     if (total_dgrad_units) hipLaunchKernelGGL((pack_dgrad_kernel<float>), dim3(total_dgrad_units), dim3(256), 0, stream, jobs_dev, njobs);
   }
   MIREG_LAUNCH_RET();
@@ -486,6 +566,24 @@ int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, int total_unit
   MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units > 0);
   const int g = total_units / 4 + 1 < 2048 ? total_units / 4 + 1 : 2048;
   hipLaunchKernelGGL((pack_fwd_kernel<float, 1>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_wgrad_reduce(const mireg_wopt_job* jobs_dev, int njobs, int total_runits, hipStream_t stream) {
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_runits > 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(total_runits), dim3(256), 0, stream, jobs_dev, njobs);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_adam_pack(const mireg_wopt_job* jobs_dev, int njobs, int total_units, int max_taps, int* step_dev, int tick, float lr,
+                    float beta1, float beta2, float eps, float grad_scale, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units > 0 && step_dev && max_taps > 0 && max_taps <= kOptMaxTaps &&
+                  (dtype == MIREG_DTYPE_F32 || dtype == MIREG_DTYPE_BF16));
+  if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, step_dev);
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((adam_pack_kernel<__bf16>), dim3(total_units), dim3(256), 0, stream, jobs_dev, njobs, step_dev, lr, beta1, beta2, eps, grad_scale);
+  else
+    hipLaunchKernelGGL((adam_pack_kernel<float>), dim3(total_units), dim3(256), 0, stream, jobs_dev, njobs, step_dev, lr, beta1, beta2, eps, grad_scale);
   MIREG_LAUNCH_RET();
 }
 
@@ -575,7 +673,7 @@ int mireg_adam_step(const mireg_adam_job* jobs_dev, int njobs, int* step_dev, fl
                     float grad_scale, hipStream_t stream) {
   MIREG_CHECK_ARG(jobs_dev && njobs > 0 && step_dev);
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, step_dev);
-  hipLaunchKernelGGL(adam_kernel, dim3(njobs == 1 ? 4096 : 256, njobs), dim3(256), 0, stream, jobs_dev, step_dev, lr, beta1, beta2, eps, grad_scale);
+  hipLaunchKernelGGL(adam_kernel, dim3(njobs == 1 ? 4096 : (njobs <= 8 ? 256 : 8), njobs), dim3(256), 0, stream, jobs_dev, step_dev, lr, beta1, beta2, eps, grad_scale);
   MIREG_LAUNCH_RET();
 }
 

@@ -64,6 +64,13 @@ class PackJob(ctypes.Structure):
                 ("nsplit", ctypes.c_int), ("accumulate", ctypes.c_int), ("unit0", ctypes.c_int), ("dunit0", ctypes.c_int)]
 
 
+class WoptJob(ctypes.Structure):
+    _fields_ = [("slab", ctypes.c_void_p), ("slab_stride", ctypes.c_long), ("nsplit", ctypes.c_int),
+                ("g", ctypes.c_void_p), ("p", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("F", ctypes.c_void_p), ("Co", ctypes.c_int), ("Ci", ctypes.c_int), ("taps", ctypes.c_int),
+                ("Cpad", ctypes.c_int), ("ld", ctypes.c_long), ("runit0", ctypes.c_int), ("unit0", ctypes.c_int)]
+
+
 class AdamJob(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
                 ("n", ctypes.c_long)]
@@ -175,7 +182,7 @@ class LaunchProfiler:
         self.enabled = False
         self.records = []          # (kernel family, flops, start event, stop event)
 
-    def launch(self, fn: str, desc, family: str, flops: float) -> None:
+    def launch(self, fn: str, desc, family: str, flops: float, tag: str = "") -> None:
         if not self.enabled:
             _lib.call(fn, ctypes.byref(desc), _stream())
             return
@@ -183,12 +190,12 @@ class LaunchProfiler:
         a.record()
         _lib.call(fn, ctypes.byref(desc), _stream())
         b.record()
-        self.records.append((family, flops, a, b))
+        self.records.append((family, flops, a, b, tag))
 
     def summary(self) -> Dict[str, dict]:
         torch.cuda.synchronize()
         out: Dict[str, dict] = {}
-        for fam, fl, a, b in self.records:
+        for fam, fl, a, b, _ in self.records:
             d = out.setdefault(fam, {"launches": 0, "flops": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += fl
@@ -239,6 +246,7 @@ class ConvLayer:
         self.n_slots = 1
         self.grad_w: Optional[torch.Tensor] = None
         self.grad_b: Optional[torch.Tensor] = None
+        self.gpack: Optional[torch.Tensor] = None       # packed-domain gradient [Co][Kf] (view of the trainer's flat buffer)
 
     # ---- pack jobs ----------------------------------------------------------------------------
     def pack_jobs(self) -> List[PackJob]:
@@ -252,8 +260,26 @@ class ConvLayer:
             j.cls[i] = PackClass(c["pack"].data_ptr(), c["pack"].shape[1], c["ky0"], c["kx0"], c["nty"], c["ntx"])
         return [j]
 
+    def bind_gpack(self, gpack: torch.Tensor) -> None:
+        """Packed-domain gradient target.  A layer whose wgrad needs no split writes it directly (no reduce)."""
+        self.gpack = gpack
+        if self.wgrad_slab is not None and self.wgrad_split * self.n_slots == 1:
+            self.wgrad_slab = gpack.view(1, self.Co, self.Kf)
+
+    def wopt_job(self, m: int = 0, v: int = 0) -> WoptJob:
+        """Reduce (+ optimizer when m, v are given) job of this layer in the packed domain."""
+        assert self.wgrad_slab is not None and self.gpack is not None, self.name
+        j = WoptJob()
+        direct = self.wgrad_slab.data_ptr() == self.gpack.data_ptr()
+        j.slab, j.slab_stride, j.nsplit = self.wgrad_slab.data_ptr(), self.Co * self.Kf, 0 if direct else self.wgrad_split * self.n_slots
+        j.g, j.p, j.m, j.v, j.F = self.gpack.data_ptr(), self.weight.data_ptr(), m, v, self.packF.data_ptr()
+        j.Co, j.Ci, j.taps, j.Cpad, j.ld = self.Co, self.Ci, self.kh * self.kw, self.Cip, self.Kf
+        return j
+
     def unpack_job(self, accumulate: bool = False) -> PackJob:
-        assert self.wgrad_slab is not None and self.grad_w is not None
+        if self.grad_w is None:
+            self.grad_w = torch.zeros_like(self.weight, dtype=F32)
+        assert self.wgrad_slab is not None
         j = PackJob()
         j.src, j.dst = self.wgrad_slab.data_ptr(), self.grad_w.data_ptr()
         j.Co, j.Ci, j.kh, j.kw = self.Co, self.Ci, self.kh, self.kw
@@ -298,7 +324,8 @@ class ConvLayer:
         d.slope, d.accumulate = slope, int(accumulate)
         self._finish(d, x.B * Ho * Wo, self.Co, self.Kf, True)
         PROFILER.launch("mireg_conv_gemm", d, self._family(self.Co, d.split_k),
-                        2.0 * x.B * Ho * Wo * self.Co * self.kh * self.kw * self.Ci)
+                        2.0 * x.B * Ho * Wo * self.Co * self.kh * self.kw * self.Ci,
+                        f"{self.name}:fwd M={x.B * Ho * Wo} N={self.Co} K={self.Kf} split={d.split_k}")
 
     @staticmethod
     def _family(N: int, split: int) -> str:
@@ -353,7 +380,8 @@ class ConvLayer:
         Mmax = max(g.B * gh * gw for _, gh, gw in live)
         Kmin = min(c["K"] for c, _, _ in live)
         self._finish(d, Mmax, self.Ci, Kmin, True, len(live))
-        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Ci, d.split_k), flops)
+        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Ci, d.split_k), flops,
+                        f"{self.name}:dgrad M={Mmax}x{len(live)} N={self.Ci} K={Kmin} split={d.split_k}")
 
     def plan_wgrad(self, x: View, dy: View) -> None:
         """Size the persistent split-K slab for dW[co][(ky,kx,ci_pad)] = sum_pix dy[pix][co] x[pix@tap][ci]."""
@@ -361,8 +389,11 @@ class ConvLayer:
         tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
         nk = (dy.rows + bk - 1) // bk
         self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU + tiles - 1) // tiles, max(nk // 8, 1), 192))
-        self.wgrad_slab = torch.zeros(self.n_slots * self.wgrad_split, self.Co, self.Kf, device=self.ws.device, dtype=F32)
-        if self.grad_w is None:
+        if self.gpack is not None and self.n_slots * self.wgrad_split == 1:
+            self.wgrad_slab = self.gpack.view(1, self.Co, self.Kf)
+        else:
+            self.wgrad_slab = torch.zeros(self.n_slots * self.wgrad_split, self.Co, self.Kf, device=self.ws.device, dtype=F32)
+        if self.grad_w is None and self.gpack is None:
             self.grad_w = torch.zeros_like(self.weight, dtype=F32)
         if self.bias is not None and self.grad_b is None:
             self.grad_b = torch.zeros_like(self.bias, dtype=F32)
@@ -385,7 +416,8 @@ class ConvLayer:
         d.slab = self.wgrad_slab[slot * self.wgrad_split].data_ptr()
         d.x_bytes, d.w_bytes = x.bytes_left, dy.bytes_left          # w_bytes carries the dy extent in WGRAD mode
         PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_kernel<128,128>",
-                        2.0 * dy.rows * self.Co * self.kh * self.kw * self.Ci)
+                        2.0 * dy.rows * self.Co * self.kh * self.kw * self.Ci,
+                        f"{self.name}:wgrad M={self.Co} N={self.Kf} K={dy.rows} split={d.split_k}")
 
     def run_bias_grad(self, dy: View, accumulate: bool = False) -> None:
         if self.bias is None:

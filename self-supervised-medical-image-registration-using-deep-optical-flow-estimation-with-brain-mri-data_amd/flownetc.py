@@ -158,7 +158,7 @@ class _FlowNetCFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *g):
         eng = ctx.eng
-        eng.backward(g if eng.training_cache else (g[0], None, None, None, None))
+        eng.autograd_backward(g if eng.training_cache else (g[0], None, None, None, None))
         table = eng.param_grads()
         grads = tuple(table[id(p)].clone() if id(p) in table else None for p in ctx.module.parameters())
         return (None, None) + grads

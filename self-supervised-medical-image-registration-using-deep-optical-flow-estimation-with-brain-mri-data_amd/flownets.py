@@ -43,6 +43,7 @@ class PredictorEngineBase:
         self._pack_table = None
         self._pack_key = None
         self._unpack_table = None
+        self._reduce_table = {}
         self.training_cache = False
 
     # -- parameters ---------------------------------------------------------------------------------
@@ -73,18 +74,29 @@ class PredictorEngineBase:
         if getattr(self, "_side", None) is not None:
             torch.cuda.current_stream().wait_stream(self._side)
 
-    def pack_weights(self) -> None:
+    # "torch": backward ends in torch-layout gradients (autograd drop-in);  "packed": it ends in the packed-domain
+    # flat gradient the fused optimizer consumes (RegistrationTrainer), and the optimizer keeps the packs fresh.
+    grad_mode = "torch"
+    packs_fresh = False
+
+    def pack_weights(self, force: bool = False, dgrad_only: bool = False) -> None:
         """torch-layout fp32 parameters -> GEMM packs (one table-driven launch)."""
+        if self.packs_fresh and not force and not dgrad_only:
+            return
         key = tuple(l.weight.data_ptr() for l in self.layers.values())
         if self._pack_key != key:
             jobs = [j for l in self.layers.values() for j in l.pack_jobs()]
             self._pack_units, self._pack_dunits = assign_tiles(jobs, False)
             self._pack_table, self._pack_n, self._pack_key = upload_table(jobs, self.ws.device), len(jobs), key
-        _lib.call("mireg_pack_weights", self._pack_table.data_ptr(), self._pack_n, self._pack_units, self._pack_dunits,
-                  self.ws.code, _stream())
+        if dgrad_only and not self._pack_dunits:
+            return
+        _lib.call("mireg_pack_weights", self._pack_table.data_ptr(), self._pack_n, 0 if dgrad_only else self._pack_units,
+                  self._pack_dunits, self.ws.code, _stream())
 
     def unpack_grads(self, names: Optional[Sequence[str]] = None) -> None:
         """wgrad slabs -> torch-layout gradients, for all layers or for the named subset (one backward phase)."""
+        if self.grad_mode == "packed":
+            return self.reduce_grads(names)
         key = tuple(names) if names is not None else None
         if self._unpack_table is None:
             self._unpack_table = {}
@@ -96,6 +108,55 @@ class PredictorEngineBase:
         tab, n, units = self._unpack_table[key]
         _lib.call("mireg_unpack_wgrad", tab.data_ptr(), n, units, _stream())
 
+    def reduce_grads(self, names: Optional[Sequence[str]] = None) -> None:
+        """split-K wgrad slabs -> packed-domain gradients for all layers or one backward phase (one launch)."""
+        key = tuple(names) if names is not None else None
+        if key not in self._reduce_table:
+            layers = [self.layers[n] for n in names] if names is not None else list(self.layers.values())
+            jobs, units = [], 0
+            for l in layers:
+                if l.wgrad_slab is None:
+                    continue
+                j = l.wopt_job()
+                if j.nsplit > 0:
+                    j.runit0 = units
+                    units += (l.Co * l.Kf + 255) // 256
+                    jobs.append(j)
+            self._reduce_table[key] = (upload_table(jobs, self.ws.device), len(jobs), units) if jobs else None
+        if self._reduce_table[key] is not None:
+            tab, n, units = self._reduce_table[key]
+            _lib.call("mireg_wgrad_reduce", tab.data_ptr(), n, units, _stream())
+
+    def packed_layout(self, params: Sequence[nn.Parameter]) -> Tuple[Dict[int, int], Dict[int, int], int]:
+        """Offsets / slot sizes (floats) of every parameter's gradient in the packed flat buffer (parameter order;
+        conv weights occupy Co*Kf, everything else numel; every slot starts 16-byte aligned)."""
+        wl = {id(l.weight): l for l in self.layers.values()}
+        off, size, o = {}, {}, 0
+        for p in params:
+            n = wl[id(p)].Co * wl[id(p)].Kf if id(p) in wl else p.numel()
+            off[id(p)], size[id(p)] = o, (n + 3) // 4 * 4
+            o += size[id(p)]
+        return off, size, o
+
+    def bind_packed_grads(self, params: Sequence[nn.Parameter], flat: torch.Tensor) -> None:
+        """Packed-domain counterpart of bind_flat_grads: `flat` (packed_layout size) receives every gradient."""
+        off, size, total = self.packed_layout(params)
+        assert total == flat.numel()
+        self.flat_off, self.flat_size = off, size
+        byid = {id(p): p for p in params}
+
+        def view(p):
+            return flat[off[id(p)]:off[id(p)] + p.numel()].view(p.shape)
+        for l in self.layers.values():
+            l.bind_gpack(flat[off[id(l.weight)]:off[id(l.weight)] + l.Co * l.Kf].view(l.Co, l.Kf))
+            l.grad_w = None
+            if l.bias is not None:
+                l.grad_b = view(l.bias)
+        for b in self.bns.values():
+            b.grad_g, b.grad_b = view(b.bn.weight), view(b.bn.bias)
+        self._unpack_table, self._reduce_table = None, {}
+        self.grad_mode = "packed"
+
     def flat_range(self, layer_names: Sequence[str], bn_names: Sequence[str] = ()) -> Tuple[int, int]:
         """[start, end) of the flat gradient buffer covered by these layers' parameters (must be contiguous)."""
         ps = []
@@ -106,9 +167,10 @@ class PredictorEngineBase:
                 ps.append(l.bias)
         for n in bn_names:
             ps += [self.bns[n].bn.weight, self.bns[n].bn.bias]
+        size = self.flat_size
         lo = min(self.flat_off[id(p)] for p in ps)
-        hi = max(self.flat_off[id(p)] + p.numel() for p in ps)
-        assert hi - lo == sum(p.numel() for p in {id(p): p for p in ps}.values()), "phase parameters are not contiguous"
+        hi = max(self.flat_off[id(p)] + size[id(p)] for p in ps)
+        assert hi - lo == sum(size[i] for i in {id(p) for p in ps}), "phase parameters are not contiguous"
         return lo, hi
 
     def bind_flat_grads(self, params: Sequence[nn.Parameter], flat: torch.Tensor) -> None:
@@ -119,7 +181,8 @@ class PredictorEngineBase:
             off[id(p)] = o
             o += p.numel()
         assert o == flat.numel()
-        self.flat_off = off
+        self.flat_off, self.flat_size = off, {id(p): p.numel() for p in params}
+        self.grad_mode = "torch"
 
         def view(p):
             return flat[off[id(p)]:off[id(p)] + p.numel()].view(p.shape)
@@ -130,6 +193,14 @@ class PredictorEngineBase:
         for b in self.bns.values():
             b.grad_g, b.grad_b = view(b.bn.weight), view(b.bn.bias)
         self._unpack_table = None
+
+    def autograd_backward(self, g) -> None:
+        """backward() ending in torch-layout gradients even when a trainer has bound this engine to the packed domain."""
+        mode, self.grad_mode = self.grad_mode, "torch"
+        try:
+            self.backward(g)
+        finally:
+            self.grad_mode = mode
 
     def param_grads(self) -> Dict[int, torch.Tensor]:
         """id(parameter) -> persistent fp32 gradient buffer (torch layout)."""
@@ -378,7 +449,7 @@ class _FlowNetSFn(torch.autograd.Function):
             g = gflows
         else:  # eval arity (flow0, flow2)
             g = (gflows[0], gflows[1], None, None, None, None)
-        eng.backward(g)
+        eng.autograd_backward(g)
         table = eng.param_grads()
         grads = tuple(table[id(p)].clone() if id(p) in table else None for p in ctx.module.parameters())
         return (None, None) + grads

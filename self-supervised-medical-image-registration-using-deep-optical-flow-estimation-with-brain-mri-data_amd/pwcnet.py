@@ -244,7 +244,7 @@ class _PWCFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *g):
-        ctx.eng.backward(g)
+        ctx.eng.autograd_backward(g)
         table = ctx.eng.param_grads()
         grads = tuple(table[id(p)].clone() if id(p) in table else None for p in ctx.module.parameters())
         return (None, None) + grads

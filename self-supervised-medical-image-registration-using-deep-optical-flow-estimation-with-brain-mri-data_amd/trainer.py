@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import dist as mdist
-from .engine import AdamJob, F32, _stream, upload_table
+from .engine import AdamJob, F32, WoptJob, _stream, upload_table
 from .ops import SLOTS
 
 
@@ -113,7 +113,7 @@ class RegistrationTrainer:
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-4,
                  lamb_da: float = 0.5, gamma: float = 100.0, zeta: float = 100.0, use_graph: bool = True,
-                 process_group=None, sync_loss_stats: bool = False, overlap: bool = True):
+                 process_group=None, sync_loss_stats: bool = False, overlap: bool = True, packed_optimizer: bool = True):
         self.model = model
         self.predictor = model.predictor
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -127,14 +127,16 @@ class RegistrationTrainer:
         self.overlap = overlap
         self._graphs = None
         self._seg_ranges = [None]
+        self.packed = packed_optimizer
+        self._packs_fresh = False
         self.flat_p = flatten_parameters(model)
         dev = self.flat_p.device
-        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_g = None if self.packed else torch.zeros_like(self.flat_p)     # packed: sized in _setup (engine layout)
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
-        self._adam_tab = upload_table([AdamJob(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                                               self.flat_v.data_ptr(), self.flat_p.numel())], dev)
+        self._adam_tab = None
+        model.register_load_state_dict_post_hook(lambda *_: self.refresh_packs())
         self.eng = None
         self.loss = None
         self.x_static = None
@@ -146,15 +148,44 @@ class RegistrationTrainer:
     def _setup(self, x: torch.Tensor) -> None:
         self.predictor.train()
         self.eng = self.predictor.engine_for(x)
-        self.eng.bind_flat_grads(list(self.model.parameters()), self.flat_g)
+        params, dev = list(self.model.parameters()), self.flat_p.device
+        if self.packed and max(l.kh * l.kw for l in self.eng.layers.values()) > 49:
+            self.packed = False
+        if self.packed:
+            # gradients live in the packed GEMM domain: conv weights as [Co][(ky,kx,ci_pad)], the rest as in torch
+            off, _, total = self.eng.packed_layout(params)
+            self.flat_g = torch.zeros(total, device=dev, dtype=F32)
+            self.eng.bind_packed_grads(params, self.flat_g)
+            wl = {id(l.weight) for l in self.eng.layers.values()}
+            jobs, o = [], 0
+            for p in params:
+                if id(p) not in wl:
+                    jobs.append(AdamJob(p.data_ptr(), self.flat_g.data_ptr() + 4 * off[id(p)], self.flat_m.data_ptr() + 4 * o,
+                                        self.flat_v.data_ptr() + 4 * o, p.numel()))
+                o += p.numel()
+            self._adam_tab, self._adam_n = upload_table(jobs, dev), len(jobs)
+            self._wopt_tab = None
+        else:
+            if self.flat_g is None:
+                self.flat_g = torch.zeros_like(self.flat_p)
+            self.eng.bind_flat_grads(params, self.flat_g)
+            self._adam_tab, self._adam_n = upload_table([AdamJob(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                                                 self.flat_v.data_ptr(), self.flat_p.numel())], dev), 1
         self.x_static = torch.empty_like(x, memory_format=torch.contiguous_format)
         flows = self.eng.forward(self.x_static.copy_(x), True)
         sizes = [tuple(f.shape[2:]) for f in flows]
         B, _, H, W = x.shape
         self.loss = FusedRegLoss(B, H, W, sizes, x.device, *self.loss_hyper)
 
+    def refresh_packs(self) -> None:
+        """Re-derive every GEMM pack from the fp32 master weights (after load_state_dict / manual edits)."""
+        if self.eng is not None:
+            self.eng.pack_weights(force=True)
+
     def _forward_and_loss(self):
+        self.eng.packs_fresh = self._packs_fresh          # the fused optimizer rewrote the packs with the weights
         flows = self.eng.forward(self.x_static, True)
+        self.eng.packs_fresh = False
         self.loss.forward(self.x_static, flows)
         Bg = self.loss.B * self.world if self.sync_loss_stats else None
         if self.sync_loss_stats:
@@ -181,8 +212,27 @@ class RegistrationTrainer:
         return [(self._fwd_bwd, None)]
 
     def _optim(self) -> None:
-        _lib.call("mireg_adam_step", self._adam_tab.data_ptr(), 1, self.step_dev.data_ptr(), self.lr, self.betas[0],
-                  self.betas[1], self.eps, 1.0 / self.world, _stream())
+        st = _stream()
+        _lib.call("mireg_adam_step", self._adam_tab.data_ptr(), self._adam_n, self.step_dev.data_ptr(), self.lr, self.betas[0],
+                  self.betas[1], self.eps, 1.0 / self.world, st)
+        if not self.packed:
+            return
+        if self._wopt_tab is None:
+            jobs, units, base = [], 0, self.flat_p.data_ptr()
+            for l in self.eng.layers.values():
+                if l.wgrad_slab is None:                      # layer outside the backward graph: weights never move
+                    continue
+                o = l.weight.data_ptr() - base
+                j = l.wopt_job(self.flat_m.data_ptr() + o, self.flat_v.data_ptr() + o)
+                j.unit0 = units
+                units += l.Co * ((l.Cip + 63) // 64)
+                jobs.append(j)
+            self._wopt_tab = (upload_table(jobs, self.flat_p.device), len(jobs), units, max(j.taps for j in jobs))
+        tab, n, units, max_taps = self._wopt_tab
+        _lib.call("mireg_adam_pack", tab.data_ptr(), n, units, max_taps, self.step_dev.data_ptr(), 0, self.lr, self.betas[0],
+                  self.betas[1], self.eps, 1.0 / self.world, self.eng.ws.code, st)
+        self.eng.pack_weights(dgrad_only=True)
+        self._packs_fresh = True
 
     def _run(self, runners) -> None:
         """runners[i]() executes segment i (eagerly or as a hipGraph replay); finished buckets are all-reduced
