@@ -156,6 +156,19 @@ int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int total_unit
                        hipStream_t stream);
 int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, int total_units, hipStream_t stream);
 
+/* ---- two-output-channel 3x3 / stride 1 / pad 1 convolutions (predict_flow heads: FlowNetS/util.py:33-34,
+ * flownet2/networks/submodules.py:32-33, PWC/models/PWCNet.py:31-32) on the vector ALUs.  w = the FWD pack
+ * [2][9*Cpad] of mireg_pack_weights; x / dx = wide NHWC tensors (Cpad channels walked, 16-byte aligned rows);
+ * y / dy = two-channel NHWC tensors.  wgrad writes `ntiles` partial slabs [ntiles][2][9*Cpad] (fp32), summed by
+ * mireg_wgrad_reduce / mireg_unpack_wgrad; ntiles must be what mireg_thin_conv_wgrad_tiles returns. */
+int mireg_thin_conv_fwd(const void* x, long ld_x, const void* w, long ld_w, const float* bias, void* y, long ld_y,
+                        float* y32, long ld_y32, int B, int H, int W, int Cpad, int dtype, hipStream_t stream);
+int mireg_thin_conv_dgrad(const void* dy, long ld_dy, const void* w, long ld_w, void* dx, long ld_dx, int accumulate,
+                          int B, int H, int W, int Cpad, int dtype, hipStream_t stream);
+int mireg_thin_conv_wgrad_tiles(int B, int H, int W, int Cpad, int dtype, int* pixels_per_lane);
+int mireg_thin_conv_wgrad(const void* x, long ld_x, const void* dy, long ld_dy, float* slab, int ntiles, int B, int H,
+                          int W, int Cpad, int dtype, hipStream_t stream);
+
 /* ---- packed-domain optimizer for the convolution weights (train.py:55-57,129 zero_grad/backward/step) ----
  * The torch-layout gradient is never materialised on the training path:
  *   mireg_wgrad_reduce : g[co][k] = sum_{z<nsplit} slab[z][co][k]       (fixed order; jobs with nsplit == 0 own no units)

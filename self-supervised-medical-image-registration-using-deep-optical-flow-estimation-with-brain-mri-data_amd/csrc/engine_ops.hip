@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const mireg_wopt_job*
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < E) {
     const float* sp = j.slab + e;
-#pragma unroll 4
+#pragma unroll 8
     for (int z = zg; z < j.nsplit; z += 4) {
       const float4 q = *GPTR(const float4, sp + (long)z * j.slab_stride);
       acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;

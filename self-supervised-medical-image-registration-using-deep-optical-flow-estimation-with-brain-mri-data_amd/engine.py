@@ -174,6 +174,9 @@ class Workspace:
 NUM_CU = 256
 
 
+USE_THIN = True     # module switch (tests compare the thin kernels with the GEMM path)
+
+
 class LaunchProfiler:
     """Optional per-launch timing of the MFMA contractions (bench.py roofline leg): brackets every
     mireg_conv_gemm / mireg_conv_wgrad launch with events on the launch stream and books its algorithmic FLOPs."""
@@ -189,6 +192,17 @@ class LaunchProfiler:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         _lib.call(fn, ctypes.byref(desc), _stream())
+        b.record()
+        self.records.append((family, flops, a, b, tag))
+
+    def call(self, family: str, flops: float, tag: str, fn: str, *args) -> None:
+        """Same bookkeeping for a plain-argument entry point."""
+        if not self.enabled:
+            _lib.call(fn, *args)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.call(fn, *args)
         b.record()
         self.records.append((family, flops, a, b, tag))
 
@@ -246,6 +260,8 @@ class ConvLayer:
         self.n_slots = 1
         self.grad_w: Optional[torch.Tensor] = None
         self.grad_b: Optional[torch.Tensor] = None
+        # two-channel 3x3 heads (predict_flow): vector-ALU streaming kernels instead of a 2-column GEMM
+        self.thin = USE_THIN and (self.Co, self.kh, self.kw, self.s, self.p, self.d) == (2, 3, 3, 1, 1, 1)
         self.gpack: Optional[torch.Tensor] = None       # packed-domain gradient [Co][Kf] (view of the trainer's flat buffer)
 
     # ---- pack jobs ----------------------------------------------------------------------------
@@ -310,6 +326,14 @@ class ConvLayer:
         Wo = (x.W + 2 * self.p - self.d * (self.kw - 1) - 1) // self.s + 1
         out = y if y is not None else y32
         assert (out.H, out.W) == (Ho, Wo), (self.name, (out.H, out.W), (Ho, Wo))
+        if self.thin and slope == 1.0 and not accumulate:
+            PROFILER.call("thin_conv_fwd", 2.0 * x.B * Ho * Wo * 2 * 9 * self.Ci, f"{self.name}:thin-fwd",
+                          "mireg_thin_conv_fwd", x.ptr, x.ld, self.packF.data_ptr(), self.Kf,
+                          self.bias.data_ptr() if (bias and self.bias is not None) else None,
+                          y.ptr if y is not None else None, y.ld if y is not None else 0,
+                          y32.ptr if y32 is not None else None, y32.ld if y32 is not None else 0,
+                          x.B, x.H, x.W, self.Cip, self.ws.code, _stream())
+            return
         d = ConvDesc()
         d.x, d.x_ld, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, x.H, x.W, self.Cip
         d.taps_y, d.taps_x = self.kh, self.kw
@@ -346,6 +370,11 @@ class ConvLayer:
         (only exact divisions contribute).  out has the LARGER spatial size."""
         assert g.C <= self.Cop and g.c0 + self.Cop <= g.ld, (self.name, g.C, self.Co, g.ld)
         o = out if out is not None else y32
+        if self.thin and out is not None and y32 is None and slope == 1.0 and not bias:
+            PROFILER.call("thin_conv_dgrad", 2.0 * g.B * g.H * g.W * 2 * 9 * self.Ci, f"{self.name}:thin-dgrad",
+                          "mireg_thin_conv_dgrad", g.ptr, g.ld, self.packF.data_ptr(), self.Kf, out.ptr, out.ld,
+                          int(accumulate), g.B, g.H, g.W, self.Cip, self.ws.code, _stream())
+            return
         live = []
         for c in self.classes:
             gH = (o.H - c["py"] + self.s - 1) // self.s
@@ -388,7 +417,10 @@ class ConvLayer:
         bk = 32 if self.ws.code == DT_BF16 else 16
         tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
         nk = (dy.rows + bk - 1) // bk
-        self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU + tiles - 1) // tiles, max(nk // 8, 1), 192))
+        if self.thin:
+            self.wgrad_split = _lib.lib().mireg_thin_conv_wgrad_tiles(dy.B, dy.H, dy.W, self.Cip, self.ws.code, None)
+        else:
+            self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU + tiles - 1) // tiles, max(nk // 8, 1), 192))
         if self.gpack is not None and self.n_slots * self.wgrad_split == 1:
             self.wgrad_slab = self.gpack.view(1, self.Co, self.Kf)
         else:
@@ -404,6 +436,12 @@ class ConvLayer:
         if self.wgrad_slab is None:
             self.plan_wgrad(x, dy)
         assert x.C <= self.Cip and x.c0 + self.Cip <= x.ld and dy.c0 + rup(self.Co, 8) <= dy.ld, self.name
+        if self.thin:
+            PROFILER.call("thin_conv_wgrad", 2.0 * dy.rows * 2 * 9 * self.Ci, f"{self.name}:thin-wgrad",
+                          "mireg_thin_conv_wgrad", x.ptr, x.ld, dy.ptr, dy.ld,
+                          self.wgrad_slab[slot * self.wgrad_split].data_ptr(), self.wgrad_split, dy.B, dy.H, dy.W,
+                          self.Cip, self.ws.code, _stream())
+            return
         d = ConvDesc()
         d.x, d.x_ld, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, x.H, x.W, self.Cip
         d.taps_y, d.taps_x = self.kh, self.kw

@@ -37,6 +37,8 @@ CASES = [  # cin, cout, k, stride, pad, dil, H, W, B, bias
     (256, 32, 1, 1, 0, 1, 16, 16, 2, True),     # conv_redir 1x1
     (512, 1024, 3, 2, 1, 1, 8, 8, 3, False),    # split-K path
     (16, 16, 3, 2, 1, 1, 30, 26, 2, True),      # odd sizes, stride 2
+    (1026, 2, 3, 1, 1, 1, 6, 6, 2, True),       # predict_flow head, wave-per-pixel thin kernels
+    (34, 2, 3, 1, 1, 1, 96, 100, 2, True),      # predict_flow head, 8-lanes-per-pixel thin kernels (>= 16k pixels)
 ]
 
 
