@@ -75,6 +75,25 @@ int mireg_ofe_finalize(const double* sums, const long* npix, int n, int B, doubl
 int mireg_ofe_bwd_coef(const double* sums, const long* npix, int n, int B, double lamb_da, double gamma,
                        double zeta, const double* g4, float* coef, hipStream_t stream);
 
+/* ---- fused multi-scale tail of the training step (train.py:50-52 + loss.py:66-84 over all flow scales) ----
+ * one launch per phase for ALL scales: job i = scale i with its own buffers; blk0 = first virtual block,
+ * blocks_i = ceil(B*h*w / 256), total_blocks = sum.  x = the (B,2,H,W) fp32 batch [fixed, moving].
+ *   mireg_tail_resize: moving_r = bilinear(moving, align_corners=True), fixed_r = bilinear(fixed, False)
+ *   mireg_tail_fwd   : warped = stn(flow, moving_r); sums[slot][0..5] += moments(warped, fixed_r), [6] += smoothness
+ *   mireg_tail_bwd   : gflow = d total / d flow from coef (mireg_ofe_bwd_coef row of the scale)
+ * same per-element arithmetic as the per-scale entry points above. */
+typedef struct mireg_tail_job {
+  const float* flow; long fsb, fsc, fsp;
+  float* moving_r; float* fixed_r; float* warped;
+  float* gflow; long gsb, gsc, gsp;
+  double* sums; const float* coef;
+  int h, w, blk0, pad_;
+} mireg_tail_job;
+int mireg_tail_resize(const mireg_tail_job* jobs_dev, int njobs, int total_blocks, const float* x, int B, int H, int W,
+                      hipStream_t stream);
+int mireg_tail_fwd(const mireg_tail_job* jobs_dev, int njobs, int total_blocks, int B, hipStream_t stream);
+int mireg_tail_bwd(const mireg_tail_job* jobs_dev, int njobs, int total_blocks, int B, hipStream_t stream);
+
 /* ---- K19: F.grid_sample(vol, F.affine_grid(theta, vol.size())), models.py:187-188 (trilinear, zeros,
  * align_corners=False); planar (B,C,D,H,W) fp32 volumes, theta (B,3,4) ---------------------------------- */
 int mireg_affine_sample3d(const float* vol, const float* theta, float* out, int B, int C, int D, int H, int W,

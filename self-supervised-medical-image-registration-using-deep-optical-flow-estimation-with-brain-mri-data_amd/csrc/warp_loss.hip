@@ -451,6 +451,129 @@ affine_sample3d_kernel(const float* __restrict__ vol, const float* __restrict__ 
   }
 }
 
+// =============================================================================================
+// Multi-scale fused tail of the training step (reference train.py:50-52 + loss.py:66-84 over the six
+// flow scales): ONE launch per phase instead of one per scale and op.  Job i = scale i; virtual block
+// ranges [blk0, blk0 + ceil(B*h*w / 256)) are laid out back to back.  Per-element arithmetic is the same
+// as the per-scale kernels above (same op order), only the partition of the moment sums differs.
+//   resize : moving_r = bilinear(moving, align_corners=True) [models.py:258], fixed_r = bilinear(fixed, False) [loss.py:11,54]
+//   fwd    : warped = stn(flow, moving_r); moments of (warped, fixed_r); smoothness sum of flow
+//   bwd    : gflow = d(total)/d(flow) = warp-backward(d loss/d warped) + smoothness gradient
+// =============================================================================================
+__device__ __forceinline__ int tail_find(const mireg_tail_job* __restrict__ jobs, int n, int blk) {
+  int lo = 0;
+  for (int i = 1; i < n; ++i) if (jobs[i].blk0 <= blk) lo = i;
+  return lo;
+}
+
+__global__ void __launch_bounds__(kThreads)
+tail_resize_kernel(const mireg_tail_job* __restrict__ jobs, int n, const float* __restrict__ x, int B, int H, int W) {
+  const mireg_tail_job j = jobs[tail_find(jobs, n, blockIdx.x)];
+  const long npix = (long)j.h * j.w, i = (long)(blockIdx.x - j.blk0) * kThreads + threadIdx.x;
+  if (i >= (long)B * npix) return;
+  const int b = (int)(i / npix);
+  const long pix = i - (long)b * npix;
+  const int y = (int)(pix / j.w), xx = (int)(pix - (long)y * j.w);
+  const float* fixed = x + (long)b * 2 * H * W;
+  const float* moving = fixed + (long)H * W;
+#pragma unroll
+  for (int align = 0; align < 2; ++align) {
+    const float sy = align ? (j.h > 1 ? (float)(H - 1) / (float)(j.h - 1) : 0.f) : (float)H / (float)j.h;
+    const float sx = align ? (j.w > 1 ? (float)(W - 1) / (float)(j.w - 1) : 0.f) : (float)W / (float)j.w;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_coord(y, sy, align, H, y0, y1, ly);
+    src_coord(xx, sx, align, W, x0, x1, lx);
+    const float* p = align ? moving : fixed;
+    const float v00 = p[(long)y0 * W + x0], v01 = p[(long)y0 * W + x1], v10 = p[(long)y1 * W + x0], v11 = p[(long)y1 * W + x1];
+    const float top = v00 * (1.f - lx) + v01 * lx, bot = v10 * (1.f - lx) + v11 * lx;
+    (align ? j.moving_r : j.fixed_r)[i] = top * (1.f - ly) + bot * ly;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+tail_fwd_kernel(const mireg_tail_job* __restrict__ jobs, int n, int B) {
+  __shared__ float red[7 * (kThreads / 64)];
+  const mireg_tail_job j = jobs[tail_find(jobs, n, blockIdx.x)];
+  const int h = j.h, w = j.w;
+  const long npix = (long)h * w, i = (long)(blockIdx.x - j.blk0) * kThreads + threadIdx.x;
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < (long)B * npix) {
+    const int b = (int)(i / npix);
+    const long pix = i - (long)b * npix;
+    const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    const float* f = j.flow + b * j.fsb + pix * j.fsp;
+    const float u = f[0], v = f[j.fsc];
+    const float px = stn_coord((float)x, u, (float)(2.0 / (double)w), (float)(w - 1));
+    const float py = stn_coord((float)y, v, (float)(2.0 / (double)h), (float)(h - 1));
+    const float fx = floorf(px), fy = floorf(py);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = px - fx, wy1 = py - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const float* img = j.moving_r + (long)b * npix;
+    const float nw = tap(img, x0, y0, w, h), ne = tap(img, x0 + 1, y0, w, h);
+    const float sw = tap(img, x0, y0 + 1, w, h), se = tap(img, x0 + 1, y0 + 1, w, h);
+    const float o = nw * (wx0 * wy0) + ne * (wx1 * wy0) + sw * (wx0 * wy1) + se * (wx1 * wy1);
+    j.warped[i] = o;
+    const float fv = j.fixed_r[i];
+    acc[0] = o; acc[1] = fv; acc[2] = o * fv; acc[3] = o * o; acc[4] = fv * fv; acc[5] = charb(fv - o);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float val = f[c * j.fsc];
+      const float dn = (y + 1 < h) ? f[c * j.fsc + (long)w * j.fsp] : 0.f;
+      const float rt = (x + 1 < w) ? f[c * j.fsc + j.fsp] : 0.f;
+      acc[6] += charb(val - dn) + charb(val - rt);
+    }
+  }
+  block_sum<7>(acc, red);
+  if (threadIdx.x == 0) {
+    double* dst = j.sums + (blockIdx.x % kSlots) * 8;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) atomicAdd(&dst[k], (double)acc[k]);
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+tail_bwd_kernel(const mireg_tail_job* __restrict__ jobs, int n, int B) {
+  const mireg_tail_job j = jobs[tail_find(jobs, n, blockIdx.x)];
+  const int h = j.h, w = j.w;
+  const long npix = (long)h * w, i = (long)(blockIdx.x - j.blk0) * kThreads + threadIdx.x;
+  if (i >= (long)B * npix) return;
+  const float cp = j.coef[0], k1 = j.coef[1], k2 = j.coef[2], mx = j.coef[3], my = j.coef[4], cs = j.coef[5];
+  const int b = (int)(i / npix);
+  const long pix = i - (long)b * npix;
+  const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+  const float* f = j.flow + b * j.fsb + pix * j.fsp;
+  // d loss / d warped (loss.py:38-50 photometric + NCC through the scale's moments)
+  const float xv = j.warped[i], yv = j.fixed_r[i];
+  const float go = -cp * charb_grad(yv - xv) - k1 * (yv - my) + k2 * (xv - mx);
+  // through the sampler
+  const float px = stn_coord((float)x, f[0], (float)(2.0 / (double)w), (float)(w - 1));
+  const float py = stn_coord((float)y, f[j.fsc], (float)(2.0 / (double)h), (float)(h - 1));
+  const float fx = floorf(px), fy = floorf(py);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = px - fx, wy1 = py - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+  const float* img = j.moving_r + (long)b * npix;
+  const float nw = tap(img, x0, y0, w, h), ne = tap(img, x0 + 1, y0, w, h);
+  const float sw = tap(img, x0, y0 + 1, w, h), se = tap(img, x0 + 1, y0 + 1, w, h);
+  float g2[2];
+  g2[0] = 0.f + go * ((ne - nw) * wy0 + (se - sw) * wy1);
+  g2[1] = 0.f + go * ((sw - nw) * wx0 + (se - ne) * wx1);
+  g2[0] *= (float)(w - 1) / (float)w * 1.f;
+  g2[1] *= (float)(h - 1) / (float)h * 1.f;
+  float* g = j.gflow + b * j.gsb + pix * j.gsp;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float val = f[c * j.fsc];
+    const float dn = (y + 1 < h) ? f[c * j.fsc + (long)w * j.fsp] : 0.f;
+    const float rt = (x + 1 < w) ? f[c * j.fsc + j.fsp] : 0.f;
+    float acc = charb_grad(val - dn) + charb_grad(val - rt);
+    if (y > 0) acc -= charb_grad(f[c * j.fsc - (long)w * j.fsp] - val);
+    if (x > 0) acc -= charb_grad(f[c * j.fsc - j.fsp] - val);
+    acc *= cs;
+    g[c * j.gsc] = g2[c] * 1.f + acc;
+  }
+}
+
 inline int grid_for(long work, int cap = 2048) {
   long g = (work + kThreads - 1) / kThreads;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -559,6 +682,25 @@ int mireg_affine_sample3d(const float* vol, const float* theta, float* out, int 
                           hipStream_t stream) {
   MIREG_CHECK_ARG(vol && theta && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
   hipLaunchKernelGGL(affine_sample3d_kernel, dim3(grid_for((long)B * D * H * W)), dim3(kThreads), 0, stream, vol, theta, out, B, C, D, H, W);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_tail_resize(const mireg_tail_job* jobs_dev, int njobs, int total_blocks, const float* x, int B, int H, int W,
+                      hipStream_t stream) {
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 16 && total_blocks > 0 && x && B > 0 && H > 0 && W > 0);
+  hipLaunchKernelGGL(tail_resize_kernel, dim3(total_blocks), dim3(kThreads), 0, stream, jobs_dev, njobs, x, B, H, W);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_tail_fwd(const mireg_tail_job* jobs_dev, int njobs, int total_blocks, int B, hipStream_t stream) {
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 16 && total_blocks > 0 && B > 0);
+  hipLaunchKernelGGL(tail_fwd_kernel, dim3(total_blocks), dim3(kThreads), 0, stream, jobs_dev, njobs, B);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_tail_bwd(const mireg_tail_job* jobs_dev, int njobs, int total_blocks, int B, hipStream_t stream) {
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 16 && total_blocks > 0 && B > 0);
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(total_blocks), dim3(kThreads), 0, stream, jobs_dev, njobs, B);
   MIREG_LAUNCH_RET();
 }
 

@@ -71,6 +71,14 @@ class WoptJob(ctypes.Structure):
                 ("Cpad", ctypes.c_int), ("ld", ctypes.c_long), ("runit0", ctypes.c_int), ("unit0", ctypes.c_int)]
 
 
+class TailJob(ctypes.Structure):
+    _fields_ = [("flow", ctypes.c_void_p), ("fsb", ctypes.c_long), ("fsc", ctypes.c_long), ("fsp", ctypes.c_long),
+                ("moving_r", ctypes.c_void_p), ("fixed_r", ctypes.c_void_p), ("warped", ctypes.c_void_p),
+                ("gflow", ctypes.c_void_p), ("gsb", ctypes.c_long), ("gsc", ctypes.c_long), ("gsp", ctypes.c_long),
+                ("sums", ctypes.c_void_p), ("coef", ctypes.c_void_p),
+                ("h", ctypes.c_int), ("w", ctypes.c_int), ("blk0", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
 class AdamJob(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
                 ("n", ctypes.c_long)]

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import dist as mdist
-from .engine import AdamJob, F32, WoptJob, _stream, upload_table
+from .engine import AdamJob, F32, TailJob, WoptJob, _stream, upload_table
 from .ops import SLOTS
 
 
@@ -57,12 +57,37 @@ class FusedRegLoss:
         self.g4 = torch.tensor([0.0, 0.0, 0.0, 1.0], device=device, dtype=torch.float64)
         self.coef = torch.zeros(n, 8, device=device, dtype=F32)
 
+    fused = True        # one launch per phase for all scales (mireg_tail_*); False = per-scale entry points
+
+    def _table(self, flows: Sequence[torch.Tensor]):
+        key = tuple((f.data_ptr(), f.stride()) for f in flows)
+        if getattr(self, "_tab_key", None) != key:
+            jobs, blk = [], 0
+            for i, (h, w) in enumerate(self.sizes):
+                f, g = flows[i], self.gflow[i]
+                sb, sc, sy, sx = f.stride()
+                j = TailJob()
+                j.flow, j.fsb, j.fsc, j.fsp = f.data_ptr(), sb, sc, (sx if w > 1 else (sy if h > 1 else 1))
+                j.moving_r, j.fixed_r, j.warped = self.moving_r[i].data_ptr(), self.fixed_r[i].data_ptr(), self.warped[i].data_ptr()
+                j.gflow, j.gsb, j.gsc, j.gsp = g.data_ptr(), 2 * h * w, h * w, 1
+                j.sums, j.coef = self.sums[i].data_ptr(), self.coef[i].data_ptr()
+                j.h, j.w, j.blk0 = h, w, blk
+                blk += (self.B * h * w + 255) // 256
+                jobs.append(j)
+            self._tab, self._tab_blocks, self._tab_key = upload_table(jobs, self.dev), blk, key
+        return self._tab, self._tab_blocks
+
     def forward(self, x: torch.Tensor, flows: Sequence[torch.Tensor]) -> torch.Tensor:
         """x: (B,2,H,W) contiguous fp32 [fixed, moving]; flows[i]: logical (B,2,h,w) fp32 (any pixel stride)."""
         B, H, W, st = self.B, self.H, self.W, _stream()
         HW = H * W
         fixed_ptr, moving_ptr = x.data_ptr(), x.data_ptr() + HW * 4
         self.sums.zero_()
+        if self.fused:
+            tab, blocks = self._table(flows)
+            _lib.call("mireg_tail_resize", tab.data_ptr(), self.n, blocks, x.data_ptr(), B, H, W, st)
+            _lib.call("mireg_tail_fwd", tab.data_ptr(), self.n, blocks, B, st)
+            return self.sums
         for i, (h, w) in enumerate(self.sizes):
             _lib.call("mireg_resize_bilinear_fwd", moving_ptr, self.moving_r[i].data_ptr(), B, 1, H, W, h, w,
                       2 * HW, HW, 1, h * w, h * w, 1, 1, st)
@@ -94,6 +119,10 @@ class FusedRegLoss:
         lamb_da, gamma, zeta = self.hyper
         _lib.call("mireg_ofe_bwd_coef", self.sums.data_ptr(), self._npix(B_global).data_ptr(), self.n, B_global or B, lamb_da,
                   gamma, zeta, self.g4.data_ptr(), self.coef.data_ptr(), st)
+        if self.fused:
+            tab, blocks = self._table(flows)
+            _lib.call("mireg_tail_bwd", tab.data_ptr(), self.n, blocks, B, st)
+            return self.gflow
         for i, (h, w) in enumerate(self.sizes):
             f = flows[i]
             sb, sc, sy, sx = f.stride()

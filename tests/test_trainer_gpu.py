@@ -128,7 +128,7 @@ def _dp_worker(rank, world, port, ret):
         tr.step(xs)
     torch.cuda.synchronize()
     assert tr._graphs is not None and len(tr._graphs) == 3
-    ret[rank] = tr.flat_p.detach().cpu().clone()
+    torch.save(tr.flat_p.detach().cpu().clone(), os.path.join(ret, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -137,9 +137,10 @@ def test_dp2_bucketed_overlap_on_one_gpu():
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    import tempfile, os
+    tmp = tempfile.mkdtemp(prefix="mireg_dp_")           # results travel as files: no manager process to lose
+    mp.spawn(_dp_worker, args=(2, port, tmp), nprocs=2, join=True)
+    ret = {r: torch.load(os.path.join(tmp, f"rank{r}.pt")) for r in range(2)}
     assert torch.equal(ret[0], ret[1])                       # replicas stay identical
     # reference: same two half-batches, gradients averaged by hand, non-overlapped single process
     import mireg
@@ -168,3 +169,31 @@ def test_dp2_bucketed_overlap_on_one_gpu():
         tr.world = 1
     diff = (tr.flat_p.cpu() - ret[0]).abs().max().item()
     assert diff < 5e-6, diff
+
+
+def test_fused_multiscale_tail_equals_per_scale_kernels():
+    """mireg_tail_{resize,fwd,bwd} (one launch for all scales) == the per-scale entry points, op for op."""
+    from mireg.trainer import FusedRegLoss
+    from mireg.synth import make_pairs
+    B, H, W = 3, 64, 64
+    sizes = [(64, 64), (16, 16), (8, 8), (5, 7), (1, 1)]
+    x, _ = make_pairs(B, H, seed=11)
+    x = x.to(DEV).contiguous()
+    g = torch.Generator().manual_seed(4)
+    flows = [(torch.randn(B, 2, h, w, generator=g) * 1.5).to(DEV) for h, w in sizes]
+    flows[1] = flows[1].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)      # NHWC-strided like the engine's
+    outs = []
+    for fused in (False, True):
+        L = FusedRegLoss(B, H, W, sizes, torch.device(DEV))
+        L.fused = fused
+        L.forward(x, flows)
+        out4 = L.finalize().clone()
+        gf = [t.clone() for t in L.backward(flows)]
+        outs.append((L.sums.sum(1).clone(), out4, gf, [w.clone() for w in L.warped]))
+    (s0, o0, g0, w0), (s1, o1, g1, w1) = outs
+    assert torch.allclose(s0, s1, rtol=1e-6, atol=1e-9)
+    assert torch.allclose(o0, o1, rtol=1e-6)
+    for a, b in zip(w0, w1):
+        assert torch.equal(a, b)
+    for a, b in zip(g0, g1):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
