@@ -246,16 +246,19 @@ bn_partial_scalar_kernel(const T* __restrict__ y, long ld_y, const T* __restrict
   }
 }
 
-// stage 2: block = 32 channels x 8 partial-row lanes; sums the partial rows in float64
+// stage 2: block = 8 channels x 32 partial-row lanes (the partial rows are few but the loads are latency-bound, so
+// they are spread over many lanes); sums in float64, fixed order
 __device__ __forceinline__ void sum_partials(const float* __restrict__ partial, int nblk, int C, int c, int rl,
-                                             double (*sh)[32][2], double& s0, double& s1) {
+                                             double (*sh)[8][2], double& s0, double& s1) {
   s0 = 0; s1 = 0;
-  if (c < C)
-    for (int b = rl; b < nblk; b += 8) { s0 += ldf(partial + (long)b * 2 * C + c); s1 += ldf(partial + (long)b * 2 * C + C + c); }
-  sh[rl][threadIdx.x & 31][0] = s0; sh[rl][threadIdx.x & 31][1] = s1;
+  if (c < C) {
+#pragma unroll 4
+    for (int b = rl; b < nblk; b += 32) { s0 += ldf(partial + (long)b * 2 * C + c); s1 += ldf(partial + (long)b * 2 * C + C + c); }
+  }
+  sh[rl][threadIdx.x & 7][0] = s0; sh[rl][threadIdx.x & 7][1] = s1;
   __syncthreads();
   if (rl == 0)
-    for (int r = 1; r < 8; ++r) { s0 += sh[r][threadIdx.x & 31][0]; s1 += sh[r][threadIdx.x & 31][1]; }
+    for (int r = 1; r < 32; ++r) { s0 += sh[r][threadIdx.x & 7][0]; s1 += sh[r][threadIdx.x & 7][1]; }
 }
 
 // forward: -> ss = [scale | shift | mean | rstd], running stats (momentum, unbiased variance)
@@ -263,8 +266,8 @@ __global__ void __launch_bounds__(256)
 bn_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C, const float* __restrict__ gamma,
                    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
                    int training, float* __restrict__ ss) {
-  __shared__ double sh[8][32][2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  __shared__ double sh[32][8][2];
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
   double s0 = 0, s1 = 0;
   if (training) sum_partials(partial, nblk, C, c, rl, sh, s0, s1);
   if (rl != 0 || c >= C) return;
@@ -289,8 +292,8 @@ bn_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C, c
 __global__ void __launch_bounds__(256)
 bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C, float* __restrict__ red,
                        float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_param_grads) {
-  __shared__ double sh[8][32][2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  __shared__ double sh[32][8][2];
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
   double s0, s1;
   sum_partials(partial, nblk, C, c, rl, sh, s0, s1);
   if (rl != 0 || c >= C) return;
@@ -298,6 +301,121 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int 
   if (dgamma) {
     dgamma[c] = (acc_param_grads ? dgamma[c] : 0.f) + (float)s1;
     dbeta[c] = (acc_param_grads ? dbeta[c] : 0.f) + (float)s0;
+  }
+}
+
+// Single-launch BatchNorm for the deep layers (few rows, many channels), where three launches are pure launch
+// latency: a block owns 2 channel granules and ALL rows; pass 1 = column sums (fixed order: per-lane serial,
+// wave xor-tree, 4 waves in order), then the owner lanes finalize, pass 2 re-reads the rows (L2-resident).
+//   FWD: out = lrelu(bn(y)), ss / running stats as bn_finalize_kernel        BWD: dy, red, dgamma, dbeta
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256)
+bn_fused_kernel(const T* __restrict__ y, long ld_y, const T* __restrict__ da, long ld_da, T* __restrict__ out, long ld_o, long M, int C,
+                const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
+                float momentum, float eps, float slope, float* __restrict__ ss, float* __restrict__ red, float* __restrict__ dgamma,
+                float* __restrict__ dbeta, int acc_param_grads) {
+  constexpr int V = VecOf<T>::N;
+  __shared__ double wsum[4][2][2 * V];
+  __shared__ float coef[2][4 * V];                      // per granule: FWD {scale, shift}, BWD {scale, shift, mean, rstd} + red in coef2
+  __shared__ float coef2[2][2 * V];
+  const int gsel = threadIdx.x & 1, rl = threadIdx.x >> 1, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gr = blockIdx.x * 2 + gsel;                 // channel granule of this thread
+  const bool gok = gr * V < C;
+  const int c0 = gr * V;
+  float sc[V], sh[V], mu[V], rs[V];
+  if (BWD && gok) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) { sc[v] = ss[c0 + v]; sh[v] = ss[C + c0 + v]; mu[v] = ss[2 * C + c0 + v]; rs[v] = ss[3 * C + c0 + v]; }
+  }
+  float a0[V], a1[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) a0[v] = a1[v] = 0.f;
+  if (gok) {
+#pragma unroll 4
+    for (long m = rl; m < M; m += 128) {
+      float yv[V];
+      ldv(y + m * ld_y + c0, yv);
+      if (!BWD) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) { a0[v] += yv[v]; a1[v] += yv[v] * yv[v]; }
+      } else {
+        float g[V];
+        ldv(da + m * ld_da + c0, g);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const float z = yv[v] * sc[v] + sh[v];
+          const float dz = g[v] * (z > 0.f ? 1.f : slope);
+          a0[v] += dz; a1[v] += dz * ((yv[v] - mu[v]) * rs[v]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+#pragma unroll
+    for (int off = 2; off < 64; off <<= 1) { a0[v] += __shfl_xor(a0[v], off, 64); a1[v] += __shfl_xor(a1[v], off, 64); }
+  if (lane < 2) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) { wsum[wid][lane][v] = (double)a0[v]; wsum[wid][lane][V + v] = (double)a1[v]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * V) {                            // one lane per (granule, channel)
+    const int gs = threadIdx.x / V, v = threadIdx.x % V, c = (blockIdx.x * 2 + gs) * V + v;
+    if (c < C) {
+      double s0 = 0, s1 = 0;
+      for (int w = 0; w < 4; ++w) { s0 += wsum[w][gs][v]; s1 += wsum[w][gs][V + v]; }
+      if (!BWD) {
+        const double m_ = s0 / (double)M;
+        double vr = s1 / (double)M - m_ * m_;
+        if (vr < 0) vr = 0;
+        const float mean = (float)m_, var = (float)vr;
+        if (running_mean) {
+          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+          const float unbiased = M > 1 ? (float)(vr * (double)M / (double)(M - 1)) : var;
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+        const float rstd = 1.f / sqrtf(var + eps);
+        const float s_ = gamma[c] * rstd, t_ = beta[c] - mean * s_;
+        ss[c] = s_; ss[C + c] = t_; ss[2 * C + c] = mean; ss[3 * C + c] = rstd;
+        coef[gs][v] = s_; coef[gs][V + v] = t_;
+      } else {
+        const float r0 = (float)(s0 / (double)M), r1 = (float)(s1 / (double)M);
+        red[c] = r0; red[C + c] = r1;
+        if (dgamma) {
+          dgamma[c] = (acc_param_grads ? dgamma[c] : 0.f) + (float)s1;
+          dbeta[c] = (acc_param_grads ? dbeta[c] : 0.f) + (float)s0;
+        }
+        coef2[gs][v] = r0; coef2[gs][V + v] = r1;
+      }
+    }
+  }
+  __syncthreads();
+  if (!gok) return;
+  float r0[V], r1[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    if (!BWD) { sc[v] = coef[gsel][v]; sh[v] = coef[gsel][V + v]; }
+    else { r0[v] = coef2[gsel][v]; r1[v] = coef2[gsel][V + v]; }
+  }
+#pragma unroll 4
+  for (long m = rl; m < M; m += 128) {
+    float yv[V], o[V];
+    ldv(y + m * ld_y + c0, yv);
+    if (!BWD) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) { const float z = yv[v] * sc[v] + sh[v]; o[v] = z > 0.f ? z : z * slope; }
+    } else {
+      float g[V];
+      ldv(da + m * ld_da + c0, g);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float z = yv[v] * sc[v] + sh[v];
+        const float dz = g[v] * (z > 0.f ? 1.f : slope);
+        const float xh = (yv[v] - mu[v]) * rs[v];
+        o[v] = sc[v] * (dz - r0[v] - xh * r1[v]);
+      }
+    }
+    stv(out + m * ld_o + c0, o);
   }
 }
 
@@ -509,6 +627,8 @@ adam_pack_kernel(const mireg_wopt_job* __restrict__ jobs, int njobs, const int* 
   }
 }
 
+constexpr long kBnFusedMaxRows = 2048;   // rows up to which BatchNorm runs as one launch (deep layers)
+
 inline int grid1(long work, int cap = 4096) {
   long g = (work + 255) / 256;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -594,11 +714,23 @@ int mireg_bn_forward(const void* y, long ld_y, void* out, long ld_o, long M, int
   MIREG_CHECK_ARG(training || (running_mean && running_var));
   const bool vec = vec_ok(dtype, C, {ld_y, ld_o}, {y, out});
   const int nblk = bn_blocks(M, C, dtype, vec);
+  if (training && vec && M <= kBnFusedMaxRows) {
+    const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4, blocks = (C / V + 1) / 2;
+    if (dtype == MIREG_DTYPE_BF16)
+      hipLaunchKernelGGL((bn_fused_kernel<__bf16, false>), dim3(blocks), dim3(256), 0, stream, (const __bf16*)y, ld_y, (const __bf16*)nullptr, 0L,
+                         (__bf16*)out, ld_o, M, C, gamma, beta, running_mean, running_var, momentum, eps, slope, ss, (float*)nullptr,
+                         (float*)nullptr, (float*)nullptr, 0);
+    else
+      hipLaunchKernelGGL((bn_fused_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, (const float*)y, ld_y, (const float*)nullptr, 0L,
+                         (float*)out, ld_o, M, C, gamma, beta, running_mean, running_var, momentum, eps, slope, ss, (float*)nullptr,
+                         (float*)nullptr, (float*)nullptr, 0);
+    MIREG_LAUNCH_RET();
+  }
   if (training) {
     if (dtype == MIREG_DTYPE_BF16) launch_partial<__bf16, false>(y, ld_y, nullptr, 0, nullptr, partial, M, C, slope, nblk, vec, stream);
     else launch_partial<float, false>(y, ld_y, nullptr, 0, nullptr, partial, M, C, slope, nblk, vec, stream);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, partial, nblk, M, C, gamma, beta, running_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, partial, nblk, M, C, gamma, beta, running_mean,
                      running_var, momentum, eps, training, ss);
   if (dtype == MIREG_DTYPE_BF16) launch_elem<__bf16, 0>(y, ld_y, nullptr, 0, out, ld_o, ss, nullptr, M, C, slope, vec, stream);
   else launch_elem<float, 0>(y, ld_y, nullptr, 0, out, ld_o, ss, nullptr, M, C, slope, vec, stream);
@@ -611,9 +743,22 @@ int mireg_bn_backward(const void* y, long ld_y, const void* da, long ld_da, void
   MIREG_CHECK_ARG(y && da && dy && ss && partial && red && M > 0 && C > 0 && C <= 4096);
   const bool vec = vec_ok(dtype, C, {ld_y, ld_da, ld_dy}, {y, da, dy});
   const int nblk = bn_blocks(M, C, dtype, vec);
+  if (vec && M <= kBnFusedMaxRows) {
+    const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4, blocks = (C / V + 1) / 2;
+    float* ssm = const_cast<float*>(ss);
+    if (dtype == MIREG_DTYPE_BF16)
+      hipLaunchKernelGGL((bn_fused_kernel<__bf16, true>), dim3(blocks), dim3(256), 0, stream, (const __bf16*)y, ld_y, (const __bf16*)da, ld_da,
+                         (__bf16*)dy, ld_dy, M, C, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0.f,
+                         slope, ssm, red, dgamma, dbeta, acc_param_grads);
+    else
+      hipLaunchKernelGGL((bn_fused_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, (const float*)y, ld_y, (const float*)da, ld_da,
+                         (float*)dy, ld_dy, M, C, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0.f,
+                         slope, ssm, red, dgamma, dbeta, acc_param_grads);
+    MIREG_LAUNCH_RET();
+  }
   if (dtype == MIREG_DTYPE_BF16) launch_partial<__bf16, true>(y, ld_y, da, ld_da, ss, partial, M, C, slope, nblk, vec, stream);
   else launch_partial<float, true>(y, ld_y, da, ld_da, ss, partial, M, C, slope, nblk, vec, stream);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, partial, nblk, M, C, red, dgamma, dbeta,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, partial, nblk, M, C, red, dgamma, dbeta,
                      acc_param_grads);
   if (dtype == MIREG_DTYPE_BF16) launch_elem<__bf16, 1>(y, ld_y, da, ld_da, dy, ld_dy, ss, red, M, C, slope, vec, stream);
   else launch_elem<float, 1>(y, ld_y, da, ld_da, dy, ld_dy, ss, red, M, C, slope, vec, stream);

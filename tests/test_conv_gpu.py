@@ -133,7 +133,7 @@ def test_batchnorm_lrelu(prec):
     tol = 2e-5 if prec == "fp32" else 2e-2
     ws = Workspace(torch.device(DEV), dt)
     g = torch.Generator().manual_seed(3)
-    for C, H, B in ((64, 16, 3), (1024, 2, 2), (36, 5, 2)):
+    for C, H, B in ((64, 16, 3), (1024, 2, 2), (36, 5, 2), (64, 48, 1), (520, 6, 3)):   # one-launch (<= 2048 rows) and three-stage paths
         y = torch.randn(B, C, H, H, generator=g) * 2 + 0.5
         if prec == "bf16":
             y = y.bfloat16().float()
