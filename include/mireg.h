@@ -147,6 +147,9 @@ typedef struct mireg_conv_desc {
    * iz = gz*mul_z + off_z + tz*step_z in [0, x_D); rows run over (n_img, g_D, g_H, g_W); k = ((tz*taps_y+ty)*taps_x+tx)*x_C + c;
    * output voxel z = gz*y_mul_z + y_off_z in a y_D deep volume.  mireg_conv_gemm only (single class). */
   int x_D, taps_z, mul_z, off_z, step_z, g_D, y_D, y_mul_z, y_off_z;
+  /* output-column tile width of mireg_conv_gemm: 0 = by N (128 / 64 / 32); 64 or 128 forces it (the host picks the
+   * width whose tile count fills the 256 CUs most evenly) */
+  int tile_n;
 } mireg_conv_desc;
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream);
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);

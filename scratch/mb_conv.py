@@ -4,6 +4,7 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 import mireg
 from mireg.engine import ConvLayer, Workspace, upload_table, _stream
 from mireg import _lib
+if os.environ.get('MIREG_LIB'): _lib.LIB_PATH = os.environ['MIREG_LIB']
 mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 cin, cout, k, s, H, B = [int(v) for v in (sys.argv[2:8] if len(sys.argv) > 7 else (256, 256, 3, 1, 32, 24))]
 prec = sys.argv[8] if len(sys.argv) > 8 else "bf16"

@@ -285,8 +285,12 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
       wait_vmcnt<2 * (A_PW + B_PW)>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifndef MIREG_ABL_NOISSUE
       issue((it + STAGES - 1) % STAGES);
+#endif
+#ifndef MIREG_ABL_NOCOMPUTE
       compute(it % STAGES);
+#endif
     }
   } else {
     for (; it < steady; ++it) {
@@ -853,10 +857,11 @@ int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
     M = m > M ? m : M;
   }
   const int z = p.split_k > 1 ? p.split_k : 1;
-  if (p.N > 64) {
+  const int bn = (p.tile_n == 64 || p.tile_n == 128) ? p.tile_n : (p.N > 64 ? 128 : (p.N > 32 ? 64 : 32));
+  if (bn == 128) {
     dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 127) / 128)), ncls, z);
     hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, stream, p);
-  } else if (p.N > 32) {
+  } else if (bn == 64) {
     dim3 grid((unsigned)(((M + 127) / 128) * ((p.N + 63) / 64)), ncls, z);
     hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, stream, p);
   } else {

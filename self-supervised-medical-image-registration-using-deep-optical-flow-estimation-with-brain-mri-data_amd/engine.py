@@ -13,6 +13,7 @@ arithmetic happens in csrc/*.hip.  Layout rules:
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -49,7 +50,7 @@ class ConvDesc(ctypes.Structure):
                 ("n_cls", ctypes.c_int), ("cls", ConvCls * 4), ("slab_cls_stride", ctypes.c_long),
                 ("x_D", ctypes.c_int), ("taps_z", ctypes.c_int), ("mul_z", ctypes.c_int), ("off_z", ctypes.c_int),
                 ("step_z", ctypes.c_int), ("g_D", ctypes.c_int), ("y_D", ctypes.c_int), ("y_mul_z", ctypes.c_int),
-                ("y_off_z", ctypes.c_int)]
+                ("y_off_z", ctypes.c_int), ("tile_n", ctypes.c_int)]
 
 
 class PackClass(ctypes.Structure):
@@ -165,6 +166,10 @@ class Workspace:
         self.code = DT_BF16 if dtype == torch.bfloat16 else DT_F32
         self.scratch: Optional[torch.Tensor] = None
         self.scratch_elems = 0
+        # launch-shape autotuning (tile width x split-K per contraction site): `tuning` is on during the trainer's
+        # discarded tuning pass, `tuned` maps a launch site to its measured-best (tile_n, split_k)
+        self.tuning = False
+        self.tuned: Dict[tuple, Tuple[int, int]] = {}
 
     def new(self, B: int, H: int, W: int, C: int, dtype: Optional[torch.dtype] = None, pad: int = 8) -> View:
         buf = torch.zeros(B, H, W, rup(C, pad), device=self.device, dtype=dtype or self.dtype)
@@ -182,6 +187,7 @@ class Workspace:
 NUM_CU = 256
 
 
+FORCE_TILE_N = int(os.environ.get('MIREG_TILE_N', '0'))   # experiments only
 USE_THIN = True     # module switch (tests compare the thin kernels with the GEMM path)
 
 
@@ -312,19 +318,57 @@ class ConvLayer:
         return j
 
     # ---- launches -----------------------------------------------------------------------------
-    def _finish(self, d: ConvDesc, M: int, N: int, K: int, allow_split: bool, ncls: int = 1) -> None:
+    def _finish(self, d: ConvDesc, M: int, N: int, K: int, allow_split: bool, ncls: int = 1, site: str = "") -> None:
         """M = rows of the largest class, K = smallest class K (bounds the split)."""
         bk = 32 if self.ws.code == DT_BF16 else 16
-        bn = 128 if N > 64 else (64 if N > 32 else 32)
-        tiles = ((M + 127) // 128) * ((N + bn - 1) // bn) * ncls
         nk = (K + bk - 1) // bk
-        split = _split_for(tiles, nk) if allow_split else 1
-        d.split_k = split
-        if split > 1:
-            d.slab_cls_stride = split * M * N
-            self.ws.need_scratch(ncls * split * M * N)
-            d.slab = self.ws.get_scratch().data_ptr()
         d.dtype = self.ws.code
+
+        def apply(bn: int, split: int) -> None:
+            d.tile_n = bn if N > 64 else 0
+            d.split_k = split
+            if split > 1:
+                d.slab_cls_stride = split * M * N
+                self.ws.need_scratch(ncls * split * M * N)
+                d.slab = self.ws.get_scratch().data_ptr()
+
+        def tiles_for(bn: int) -> int:
+            return ((M + 127) // 128) * ((N + bn - 1) // bn) * ncls
+        bn = 128 if N > 64 else (64 if N > 32 else 32)
+        if FORCE_TILE_N and N > 64:
+            bn = FORCE_TILE_N
+        key = (self.name, site, M, N, K, ncls)
+        if key in self.ws.tuned:
+            apply(*self.ws.tuned[key])
+            return
+        heur = (bn, _split_for(tiles_for(bn), nk) if allow_split else 1)
+        if not (self.ws.tuning and allow_split and site):
+            apply(*heur)
+            return
+        # measured choice: every (tile width, split) whose grid is neither starved nor absurdly oversubscribed
+        cands = {heur}
+        for b in ((128, 64) if N > 64 else (bn,)):
+            t = tiles_for(b)
+            for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32):
+                if sp <= max(nk // 4, 1) and 96 <= t * sp <= 2304 and ncls * sp * M * N <= (1 << 26):
+                    cands.add((b, sp))
+        best, best_t = heur, float("inf")
+        st = _stream()
+        for c in sorted(cands):
+            apply(*c)
+            _lib.call("mireg_conv_gemm", ctypes.byref(d), st)
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                _lib.call("mireg_conv_gemm", ctypes.byref(d), st)
+            b_.record()
+            b_.synchronize()
+            t = a.elapsed_time(b_)
+            if t < best_t:
+                best, best_t = c, t
+        self.ws.tuned[key] = best
+        d.slab = None
+        apply(*best)
 
     def run_fwd_form(self, x: View, y: Optional[View], *, y32: Optional[View] = None, slope: float = 1.0,
                      bias: bool = True, accumulate: bool = False) -> None:
@@ -354,14 +398,14 @@ class ConvLayer:
         self._fill_out(d, y, y32, Ho, Wo, 1, 1, 0, 0)
         d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
         d.slope, d.accumulate = slope, int(accumulate)
-        self._finish(d, x.B * Ho * Wo, self.Co, self.Kf, True)
-        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Co, d.split_k),
+        self._finish(d, x.B * Ho * Wo, self.Co, self.Kf, True, site="fwd" + ("+acc" if accumulate else ""))
+        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Co, d.split_k, d.tile_n),
                         2.0 * x.B * Ho * Wo * self.Co * self.kh * self.kw * self.Ci,
                         f"{self.name}:fwd M={x.B * Ho * Wo} N={self.Co} K={self.Kf} split={d.split_k}")
 
     @staticmethod
-    def _family(N: int, split: int) -> str:
-        bn = 128 if N > 64 else (64 if N > 32 else 32)
+    def _family(N: int, split: int, tile_n: int = 0) -> str:
+        bn = tile_n or (128 if N > 64 else (64 if N > 32 else 32))
         return f"conv_gemm_kernel<128,{bn}>" + ("+splitk" if split > 1 else "")
 
     @staticmethod
@@ -416,8 +460,8 @@ class ConvLayer:
         d.n_cls = len(live) if len(live) > 1 else 0
         Mmax = max(g.B * gh * gw for _, gh, gw in live)
         Kmin = min(c["K"] for c, _, _ in live)
-        self._finish(d, Mmax, self.Ci, Kmin, True, len(live))
-        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Ci, d.split_k), flops,
+        self._finish(d, Mmax, self.Ci, Kmin, True, len(live), site="dgrad" + ("+acc" if accumulate else ""))
+        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Ci, d.split_k, d.tile_n), flops,
                         f"{self.name}:dgrad M={Mmax}x{len(live)} N={self.Ci} K={Kmin} split={d.split_k}")
 
     def plan_wgrad(self, x: View, dy: View) -> None:

@@ -142,7 +142,8 @@ class RegistrationTrainer:
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-4,
                  lamb_da: float = 0.5, gamma: float = 100.0, zeta: float = 100.0, use_graph: bool = True,
-                 process_group=None, sync_loss_stats: bool = False, overlap: bool = True, packed_optimizer: bool = True):
+                 process_group=None, sync_loss_stats: bool = False, overlap: bool = True, packed_optimizer: bool = True,
+                 autotune: bool = True):
         self.model = model
         self.predictor = model.predictor
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -157,6 +158,7 @@ class RegistrationTrainer:
         self._graphs = None
         self._seg_ranges = [None]
         self.packed = packed_optimizer
+        self.autotune = autotune
         self._packs_fresh = False
         self.flat_p = flatten_parameters(model)
         dev = self.flat_p.device
@@ -205,11 +207,28 @@ class RegistrationTrainer:
         sizes = [tuple(f.shape[2:]) for f in flows]
         B, _, H, W = x.shape
         self.loss = FusedRegLoss(B, H, W, sizes, x.device, *self.loss_hyper)
+        if self.autotune:
+            self._autotune()
 
     def refresh_packs(self) -> None:
         """Re-derive every GEMM pack from the fp32 master weights (after load_state_dict / manual edits)."""
         if self.eng is not None:
             self.eng.pack_weights(force=True)
+
+    def _autotune(self) -> None:
+        """One discarded forward+backward in which every contraction site times its candidate launch shapes
+        (tile width x split-K) on the real buffers and keeps the fastest; BatchNorm running statistics are restored."""
+        bufs = [b for b in self.model.buffers()]
+        saved = [b.detach().clone() for b in bufs]
+        ws, side = self.eng.ws, type(self.eng).use_side_stream
+        ws.tuning, self.eng.use_side_stream = True, False
+        try:
+            self._fwd_bwd()
+            torch.cuda.synchronize()
+        finally:
+            ws.tuning, self.eng.use_side_stream = False, side
+            for b, v in zip(bufs, saved):
+                b.copy_(v)
 
     def _forward_and_loss(self):
         self.eng.packs_fresh = self._packs_fresh          # the fused optimizer rewrote the packs with the weights
