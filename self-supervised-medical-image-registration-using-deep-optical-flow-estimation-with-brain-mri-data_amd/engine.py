@@ -482,6 +482,52 @@ class ConvLayer:
         if self.bias is not None and self.grad_b is None:
             self.grad_b = torch.zeros_like(self.bias, dtype=F32)
 
+    def _wgrad_desc(self, x: View, dy: View, split: int, slab_ptr: int) -> ConvDesc:
+        d = ConvDesc()
+        d.x, d.x_ld, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, x.H, x.W, self.Cip
+        d.taps_y, d.taps_x = self.kh, self.kw
+        d.mul_y = d.mul_x = self.s
+        d.off_y = d.off_x = -self.p
+        d.step_y = d.step_x = self.d
+        d.g_H, d.g_W, d.n_img = dy.H, dy.W, dy.B
+        d.y, d.y_ld, d.N = dy.ptr, dy.ld, self.Co
+        d.split_k, d.dtype = split, self.ws.code
+        d.slab = slab_ptr
+        d.x_bytes, d.w_bytes = x.bytes_left, dy.bytes_left          # w_bytes carries the dy extent in WGRAD mode
+        return d
+
+    def _tune_wgrad(self, x: View, dy: View) -> None:
+        """Measured split-K of the backward-weights GEMM: kernel time + the cost of summing its slabs afterwards."""
+        bk = 32 if self.ws.code == DT_BF16 else 16
+        tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
+        nk = (dy.rows + bk - 1) // bk
+        elems = self.Co * self.Kf
+        cands = {self.wgrad_split}
+        for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32, 44, 64, 96, 128, 192):
+            if sp <= max(nk // 8, 1) and 128 <= tiles * sp <= 2304 and sp * elems <= (1 << 26):
+                cands.add(sp)
+        tmp = torch.empty(max(cands) * elems, device=self.ws.device, dtype=F32)
+        best, best_t, st = self.wgrad_split, float("inf"), _stream()
+        for sp in sorted(cands):
+            d = self._wgrad_desc(x, dy, sp, tmp.data_ptr())
+            _lib.call("mireg_conv_wgrad", ctypes.byref(d), st)
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                _lib.call("mireg_conv_wgrad", ctypes.byref(d), st)
+            b_.record()
+            b_.synchronize()
+            t = a.elapsed_time(b_) / 3 + (sp * elems * 4 / 3.0e9 if sp > 1 else 0.0)     # ms; slabs re-read at ~3 TB/s
+            if t < best_t:
+                best, best_t = sp, t
+        self._wgrad_tuned = True
+        if best != self.wgrad_split:
+            self.wgrad_split = best
+            if self.gpack is not None and self.n_slots * best == 1:
+                self.wgrad_slab = self.gpack.view(1, self.Co, self.Kf)
+            else:
+                self.wgrad_slab = torch.zeros(self.n_slots * best, self.Co, self.Kf, device=self.ws.device, dtype=F32)
+
     def run_wgrad(self, x: View, dy: View, slot: int = 0) -> None:
         """x: tensor in this conv's INPUT space (C = Ci), dy: tensor in its OUTPUT space (C = Co).
         slot selects the slab group of a weight-shared layer (the unpack sums all groups)."""
@@ -494,17 +540,9 @@ class ConvLayer:
                           self.wgrad_slab[slot * self.wgrad_split].data_ptr(), self.wgrad_split, dy.B, dy.H, dy.W,
                           self.Cip, self.ws.code, _stream())
             return
-        d = ConvDesc()
-        d.x, d.x_ld, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, x.H, x.W, self.Cip
-        d.taps_y, d.taps_x = self.kh, self.kw
-        d.mul_y = d.mul_x = self.s
-        d.off_y = d.off_x = -self.p
-        d.step_y = d.step_x = self.d
-        d.g_H, d.g_W, d.n_img = dy.H, dy.W, dy.B
-        d.y, d.y_ld, d.N = dy.ptr, dy.ld, self.Co
-        d.split_k, d.dtype = self.wgrad_split, self.ws.code
-        d.slab = self.wgrad_slab[slot * self.wgrad_split].data_ptr()
-        d.x_bytes, d.w_bytes = x.bytes_left, dy.bytes_left          # w_bytes carries the dy extent in WGRAD mode
+        if self.ws.tuning and not getattr(self, "_wgrad_tuned", False):
+            self._tune_wgrad(x, dy)
+        d = self._wgrad_desc(x, dy, self.wgrad_split, self.wgrad_slab[slot * self.wgrad_split].data_ptr())
         PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_kernel<128,128>",
                         2.0 * dy.rows * self.Co * self.kh * self.kw * self.Ci,
                         f"{self.name}:wgrad M={self.Co} N={self.Kf} K={dy.rows} split={d.split_k}")

@@ -229,6 +229,7 @@ class RegistrationTrainer:
             ws.tuning, self.eng.use_side_stream = False, side
             for b, v in zip(bufs, saved):
                 b.copy_(v)
+            self.eng._reduce_table, self.eng._unpack_table = {}, None     # wgrad slabs may have been re-sized
 
     def _forward_and_loss(self):
         self.eng.packs_fresh = self._packs_fresh          # the fused optimizer rewrote the packs with the weights
