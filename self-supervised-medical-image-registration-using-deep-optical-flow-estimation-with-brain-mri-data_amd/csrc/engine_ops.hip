@@ -63,9 +63,12 @@ __device__ __forceinline__ int find_job(const mireg_pack_job* jobs, int njobs, i
   return lo;
 }
 
-__device__ __forceinline__ int find_job_d(const mireg_pack_job* jobs, int njobs, int unit) {
-  int lo = 0;
-  for (int i = 1; i < njobs; ++i) if (GPTR(const mireg_pack_job, jobs + i)->dunit0 <= unit) lo = i;
+__device__ __forceinline__ int find_job_d(const mireg_pack_job* __restrict__ jobs, int njobs, int unit) {
+  int lo = 0, hi = njobs;                                // last job with dunit0 <= unit (unit0 sequences are non-decreasing)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (jobs[mid].dunit0 <= unit) lo = mid; else hi = mid;
+  }
   return lo;
 }
 
@@ -144,33 +147,43 @@ __global__ void __launch_bounds__(256) pack_fwd_kernel(const mireg_pack_job* __r
 // DGRAD packs from the FWD pack: D_c[ci][tt*Cop + co] = F[co][tap*Cip + ci]; block = (64 co x 64 ci) of one (class, tt)
 template <typename T>
 __global__ void __launch_bounds__(256) pack_dgrad_kernel(const mireg_pack_job* __restrict__ jobs, int njobs) {
-  __shared__ T tile[64][64 + 2];
-  const mireg_pack_job j = *GPTR(const mireg_pack_job, jobs + find_job_d(jobs, njobs, blockIdx.x));
-  const int co_t = (j.Cop + 63) / 64, ci_t = (j.Ci + 63) / 64;
-  int u = blockIdx.x - j.dunit0, c = 0;
-  for (; c < j.nclass; ++c) {                           // which class / tap / tile
-    const int n = j.cls[c].nty * j.cls[c].ntx * co_t * ci_t;
+  __shared__ __attribute__((aligned(16))) T tile[64][64 + VecOf<T>::N];
+  // every field is read through the (block-uniform) table pointer: scalar loads, no private copy of the struct
+  const mireg_pack_job* __restrict__ jp = jobs + find_job_d(jobs, njobs, blockIdx.x);
+  struct { int Co, Ci, Cpad, Cop, kw, stride; long ld; const void* dst; } j = {jp->Co, jp->Ci, jp->Cpad, jp->Cop, jp->kw, jp->stride, jp->ld, jp->dst};
+  const int co_t = (j.Cop + 63) / 64, ci_t = (j.Ci + 63) / 64, nclass = jp->nclass;
+  int u = blockIdx.x - jp->dunit0, c = 0;
+  for (; c < nclass - 1; ++c) {                         // which class / tap / tile
+    const int n = jp->cls[c].nty * jp->cls[c].ntx * co_t * ci_t;
     if (u < n) break;
     u -= n;
   }
-  const mireg_pack_class k = j.cls[c];
+  const mireg_pack_class* __restrict__ kp = jp->cls + c;
+  struct { void* dst; long ld; int ky0, kx0, ntx; } k = {kp->dst, kp->ld, kp->ky0, kp->kx0, kp->ntx};
   const int tt = u / (co_t * ci_t), rem = u - tt * (co_t * ci_t);
   const int co0 = (rem / ci_t) * 64, ci0 = (rem % ci_t) * 64;
   const int ty = tt / k.ntx, tx = tt - ty * k.ntx;
   const int tap = (k.ky0 + j.stride * ty) * j.kw + k.kx0 + j.stride * tx;
-  const int lane = threadIdx.x & 63, wr = threadIdx.x >> 6;
+  constexpr int V = VecOf<T>::N, CH = 64 / V;              // 16-byte granules per 64-wide tile row
   const T* F = reinterpret_cast<const T*>(j.dst);
-  for (int r = wr; r < 64; r += 4) {                    // rows = co, lanes = ci
-    const int co = co0 + r, ci = ci0 + lane;
-    T v = (T)0.f;
-    if (co < j.Co && ci < j.Cpad) v = *GPTR(const T, F + (long)co * j.ld + (long)tap * j.Cpad + ci);
-    tile[r][lane] = v;
+  for (int idx = threadIdx.x; idx < 64 * CH; idx += 256) {   // rows = co, granules along ci: 16-byte loads
+    const int r = idx / CH, ch = idx - r * CH;
+    const int co = co0 + r, ci = ci0 + ch * V;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (co < j.Co && ci < j.Cpad) v = *GPTR(const uint4, F + (long)co * j.ld + (long)tap * j.Cpad + ci);
+    *reinterpret_cast<uint4*>(&tile[r][ch * V]) = v;
   }
   __syncthreads();
   T* D = reinterpret_cast<T*>(k.dst);
-  for (int r = wr; r < 64; r += 4) {                    // rows = ci, lanes = co
-    const int ci = ci0 + r, co = co0 + lane;
-    if (ci < j.Ci && co < j.Cop) *GPTR(T, D + (long)ci * k.ld + (long)tt * j.Cop + co) = tile[lane][r];
+  for (int idx = threadIdx.x; idx < 64 * CH; idx += 256) {   // rows = ci, granules along co: gather V, 16-byte stores
+    const int r = idx / CH, ch = idx - r * CH;               // 8 (4) lanes cover one 128-byte (64-byte) run of a D row
+    const int ci = ci0 + r, co = co0 + ch * V;
+    if (ci < j.Ci && co < j.Cop) {
+      T v[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = tile[ch * V + e][r];
+      *GPTR(uint4, D + (long)ci * k.ld + (long)tt * j.Cop + co) = *reinterpret_cast<const uint4*>(v);
+    }
   }
 }
 
@@ -552,11 +565,11 @@ adam_kernel(const mireg_adam_job* __restrict__ jobs, const int* __restrict__ ste
 // packed-domain optimizer: split-K wgrad slabs -> packed gradient -> Adam on the torch-layout master
 // weights -> refreshed FWD pack, without ever materialising the torch-layout gradient.
 // ==============================================================================================
-__device__ __forceinline__ int find_wopt(const mireg_wopt_job* jobs, int njobs, int unit, bool reduce) {
-  int lo = 0;
-  for (int i = 1; i < njobs; ++i) {
-    const mireg_wopt_job* j = GPTR(const mireg_wopt_job, jobs + i);
-    if ((reduce ? j->runit0 : j->unit0) <= unit) lo = i;
+__device__ __forceinline__ int find_wopt(const mireg_wopt_job* __restrict__ jobs, int njobs, int unit, bool reduce) {
+  int lo = 0, hi = njobs;                                // last job whose first unit is <= unit (block-uniform: scalar loads)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((reduce ? jobs[mid].runit0 : jobs[mid].unit0) <= unit) lo = mid; else hi = mid;
   }
   return lo;
 }
@@ -564,7 +577,7 @@ __device__ __forceinline__ int find_wopt(const mireg_wopt_job* jobs, int njobs, 
 // g[e] = sum_z slab[z][e]; block = 256 consecutive floats (64 float4 lanes) x 4 z-groups, fixed summation order
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const mireg_wopt_job* __restrict__ jobs, int njobs) {
   __shared__ float4 part[3][64];
-  const mireg_wopt_job j = *GPTR(const mireg_wopt_job, jobs + find_wopt(jobs, njobs, blockIdx.x, true));
+  const mireg_wopt_job j = jobs[find_wopt(jobs, njobs, blockIdx.x, true)];
   const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
   const long E = (long)j.Co * j.ld, e = ((long)(blockIdx.x - j.runit0) * 64 + lane) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -592,7 +605,7 @@ __global__ void __launch_bounds__(256)
 adam_pack_kernel(const mireg_wopt_job* __restrict__ jobs, int njobs, const int* __restrict__ step, float lr, float b1, float b2,
                  float eps, float grad_scale) {
   __shared__ float tile[64 * kOptMaxTaps];
-  const mireg_wopt_job j = *GPTR(const mireg_wopt_job, jobs + find_wopt(jobs, njobs, blockIdx.x, false));
+  const mireg_wopt_job j = jobs[find_wopt(jobs, njobs, blockIdx.x, false)];
   const int taps = j.taps, tp = taps | 1, tid = threadIdx.x;
   const int chunks = (j.Cpad + 63) / 64;
   const int u = blockIdx.x - j.unit0;
