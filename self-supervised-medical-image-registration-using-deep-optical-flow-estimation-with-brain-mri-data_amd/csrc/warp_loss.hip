@@ -336,11 +336,20 @@ __device__ __forceinline__ void ncc_moments(const double* s, double N, double& s
 
 __global__ void ofe_finalize_kernel(const double* __restrict__ sums, const long* __restrict__ npix, int n, int B,
                                     double lamb, double gamma, double zeta, double* __restrict__ out4) {
+  // slot gather in parallel (lane = scale x moment, same slot order as gather_slots), closed form on lane 0
+  __shared__ double qs[16][8];
+  for (int t = threadIdx.x; t < n * 8; t += blockDim.x) {
+    const int i = t >> 3, k = t & 7;
+    double v = 0.0;
+    if (k < 7)
+      for (int sl = 0; sl < kSlots; ++sl) v += sums[((long)i * kSlots + sl) * 8 + k];
+    qs[i][k] = v;
+  }
+  __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double p = 0, c = 0, s = 0;
   for (int i = 0; i < n; ++i) {
-    double q[8];
-    gather_slots(sums, i, q);
+    const double* q = qs[i];
     const double wgt = 0.05 * (double)(i + 1);
     double sxx, syy, sxy, mx, my; bool deg;
     ncc_moments(q, (double)npix[i], sxx, syy, sxy, mx, my, deg);
@@ -667,7 +676,7 @@ int mireg_smoothness_bwd(const float* flow, long fsb, long fsc, long fsp, const 
 int mireg_ofe_finalize(const double* sums, const long* npix, int n, int B, double lamb_da, double gamma, double zeta,
                        double* out4, hipStream_t stream) {
   MIREG_CHECK_ARG(sums && npix && out4 && n > 0 && n <= 16 && B > 0);
-  hipLaunchKernelGGL(ofe_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, npix, n, B, lamb_da, gamma, zeta, out4);
+  hipLaunchKernelGGL(ofe_finalize_kernel, dim3(1), dim3(128), 0, stream, sums, npix, n, B, lamb_da, gamma, zeta, out4);
   MIREG_LAUNCH_RET();
 }
 
