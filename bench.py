@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune-cache", default=None, help="JSON of measured launch shapes (written after tuning, reused when present)")
+    ap.add_argument("--no-autotune", action="store_true", help="heuristic launch shapes (counter-collection runs: the tuning pass is slow there)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
 
@@ -110,7 +112,8 @@ def main():
             torch.distributed.broadcast(p.data, 0)
         for b in model.buffers():
             torch.distributed.broadcast(b, 0)
-    trainer = mireg.RegistrationTrainer(model, lr=1e-4, eps=1e-4, use_graph=not args.no_graph)
+    trainer = mireg.RegistrationTrainer(model, lr=1e-4, eps=1e-4, use_graph=not args.no_graph, autotune=not args.no_autotune,
+                                        tune_cache=args.tune_cache)
     x_cpu, seg_cpu = make_pairs(args.batch, args.size, seed=6 + rank)
     x = x_cpu.to(dev)
 
@@ -141,10 +144,12 @@ def main():
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     if rank == 0:
         trainer.use_graph = False
-        PROFILER.enabled, PROFILER.records = True, []
+        PROFILER.enabled, PROFILER.records, PROFILER.byte_records = True, [], []
         for _ in range(3):
             trainer._fwd_bwd()
+            trainer._optim()
         summ = PROFILER.summary()
+        hbm = PROFILER.summary(bytes_=True)
         PROFILER.enabled = False
         dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
         tot_fl = sum(v["flops"] for v in summ.values())
@@ -157,7 +162,11 @@ def main():
                 "all_contractions": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_step": round(tot_ms / 3, 3),
                                      "gflop_per_step": round(tot_fl / 3 / 1e9, 1)},
                 "families": {k: {"launches_per_step": v["launches"] // 3, "ms_per_step": round(v["ms"] / 3, 3),
-                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in summ.items()}}
+                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in summ.items()},
+                # HBM-bound kernels of the step: algorithmic bytes / event-timed duration vs 8 TB/s
+                "hbm_kernels": {k: {"launches_per_step": v["launches"] // 3, "us_per_launch": round(v["ms"] * 1e3 / v["launches"], 1),
+                                    "GBps": round(v["flops"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                    "frac_of_8TBps": round(v["flops"] / (v["ms"] * 1e-3) / 8e12, 4)} for k, v in hbm.items()}}
 
     # ---- quality leg: warped Dice of the (random-init, K-step-trained) model, GPU vs CPU oracle ---------------
     dice = None
@@ -191,11 +200,11 @@ def main():
         cpu = cpu_baseline(args.batch, args.size, args.cpu_steps, seed=6)
 
     if rank == 0:
-        out = {"metric": "registration slice-pairs/s (FlowNetS train step: fwd + warp + OFEloss + bwd + all-reduce + Adam)",
+        out = {"metric": f"registration slice-pairs/s ({args.model} train step: fwd + warp + OFEloss + bwd + all-reduce + Adam)",
                "value": round(pairs / dt, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-               "config": {"workload": f"configs[1]: {args.model} {args.size}x{args.size} slice pairs, batch {args.batch}/GPU, "
+               "config": {"workload": f"{ {'flownets': 'configs[1]', 'flownetc': 'configs[2] shape', 'pwc': 'configs[3] shape'}.get(args.model, 'custom') }: {args.model} {args.size}x{args.size} slice pairs, batch {args.batch}/GPU, "
                                       f"{args.precision} operands fp32 accumulate, train step", "global_batch": args.batch * world,
                           "parallelism": f"dp{world}", "hipgraph": not args.no_graph},
                "loss": {"photo": loss_vals[0], "corr": loss_vals[1], "smooth": loss_vals[2], "total": loss_vals[3]},

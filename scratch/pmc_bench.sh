@@ -4,7 +4,7 @@ TAG=$1; CNT=$2; PAT=$3
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$TAG
-rocprofv3 --pmc $CNT --output-format csv -d $R/gpurun_out/$TAG/pmc -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-graph > $R/gpurun_out/$TAG/out.txt 2> $R/gpurun_out/$TAG/err.txt
+rocprofv3 --pmc $CNT --output-format csv -d $R/gpurun_out/$TAG/pmc -- python3 $R/bench.py --steps 1 --warmup 3 --no-cpu-baseline --no-graph --no-autotune > $R/gpurun_out/$TAG/out.txt 2> $R/gpurun_out/$TAG/err.txt
 F=$(find $R/gpurun_out/$TAG/pmc -name "*counter_collection.csv" | head -1)
 python3 - "$F" "$PAT" <<'PY'
 import csv, sys, collections

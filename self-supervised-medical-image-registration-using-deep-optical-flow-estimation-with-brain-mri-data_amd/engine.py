@@ -170,10 +170,22 @@ class Workspace:
         # discarded tuning pass, `tuned` maps a launch site to its measured-best (tile_n, split_k)
         self.tuning = False
         self.tuned: Dict[tuple, Tuple[int, int]] = {}
+        self.tuned_wgrad: Dict[str, int] = {}              # layer name -> measured split-K of its backward-weights GEMM
 
     def new(self, B: int, H: int, W: int, C: int, dtype: Optional[torch.dtype] = None, pad: int = 8) -> View:
         buf = torch.zeros(B, H, W, rup(C, pad), device=self.device, dtype=dtype or self.dtype)
         return View(buf, B, H, W, C, 0)
+
+    def save_tuning(self, path: str) -> None:
+        import json
+        with open(path, "w") as f:
+            json.dump({"sites": [[list(k), list(v)] for k, v in self.tuned.items()], "wgrad": self.tuned_wgrad}, f)
+
+    def load_tuning(self, path: str) -> None:
+        import json
+        d = json.load(open(path))
+        self.tuned = {tuple(k): tuple(v) for k, v in d["sites"]}
+        self.tuned_wgrad = dict(d["wgrad"])
 
     def need_scratch(self, elems: int) -> None:
         self.scratch_elems = max(self.scratch_elems, elems)
@@ -197,7 +209,8 @@ class LaunchProfiler:
 
     def __init__(self):
         self.enabled = False
-        self.records = []          # (kernel family, flops, start event, stop event)
+        self.records = []          # (kernel family, flops, start event, stop event, tag)
+        self.byte_records = []     # same, for the HBM-bound kernels: (family, algorithmic bytes, start, stop, tag)
 
     def launch(self, fn: str, desc, family: str, flops: float, tag: str = "") -> None:
         if not self.enabled:
@@ -209,8 +222,8 @@ class LaunchProfiler:
         b.record()
         self.records.append((family, flops, a, b, tag))
 
-    def call(self, family: str, flops: float, tag: str, fn: str, *args) -> None:
-        """Same bookkeeping for a plain-argument entry point."""
+    def call(self, family: str, amount: float, tag: str, fn: str, *args, unit: str = "FLOP") -> None:
+        """Same bookkeeping for a plain-argument entry point; unit "B" books algorithmic HBM bytes instead of FLOPs."""
         if not self.enabled:
             _lib.call(fn, *args)
             return
@@ -218,12 +231,12 @@ class LaunchProfiler:
         a.record()
         _lib.call(fn, *args)
         b.record()
-        self.records.append((family, flops, a, b, tag))
+        (self.records if unit == "FLOP" else self.byte_records).append((family, amount, a, b, tag))
 
-    def summary(self) -> Dict[str, dict]:
+    def summary(self, bytes_: bool = False) -> Dict[str, dict]:
         torch.cuda.synchronize()
         out: Dict[str, dict] = {}
-        for fam, fl, a, b, _ in self.records:
+        for fam, fl, a, b, _ in (self.byte_records if bytes_ else self.records):
             d = out.setdefault(fam, {"launches": 0, "flops": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += fl
@@ -471,6 +484,8 @@ class ConvLayer:
         nk = (dy.rows + bk - 1) // bk
         if self.thin:
             self.wgrad_split = _lib.lib().mireg_thin_conv_wgrad_tiles(dy.B, dy.H, dy.W, self.Cip, self.ws.code, None)
+        elif self.name in self.ws.tuned_wgrad:
+            self.wgrad_split, self._wgrad_tuned = self.ws.tuned_wgrad[self.name], True
         else:
             self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU + tiles - 1) // tiles, max(nk // 8, 1), 192))
         if self.gpack is not None and self.n_slots * self.wgrad_split == 1:
@@ -521,6 +536,7 @@ class ConvLayer:
             if t < best_t:
                 best, best_t = sp, t
         self._wgrad_tuned = True
+        self.ws.tuned_wgrad[self.name] = best
         if best != self.wgrad_split:
             self.wgrad_split = best
             if self.gpack is not None and self.n_slots * best == 1:

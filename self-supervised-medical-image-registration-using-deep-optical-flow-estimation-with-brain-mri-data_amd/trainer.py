@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import dist as mdist
-from .engine import AdamJob, F32, TailJob, WoptJob, _stream, upload_table
+from .engine import PROFILER, AdamJob, F32, TailJob, WoptJob, _stream, upload_table
 from .ops import SLOTS
 
 
@@ -85,8 +85,10 @@ class FusedRegLoss:
         self.sums.zero_()
         if self.fused:
             tab, blocks = self._table(flows)
-            _lib.call("mireg_tail_resize", tab.data_ptr(), self.n, blocks, x.data_ptr(), B, H, W, st)
-            _lib.call("mireg_tail_fwd", tab.data_ptr(), self.n, blocks, B, st)
+            npx = sum(B * h * w for h, w in self.sizes)          # algorithmic HBM bytes: DESIGN.md section 6
+            PROFILER.call("tail_resize", 8.0 * B * H * W + 8.0 * npx, "tail:resize", "mireg_tail_resize", tab.data_ptr(), self.n,
+                          blocks, x.data_ptr(), B, H, W, st, unit="B")
+            PROFILER.call("tail_fwd", 20.0 * npx, "tail:fwd", "mireg_tail_fwd", tab.data_ptr(), self.n, blocks, B, st, unit="B")
             return self.sums
         for i, (h, w) in enumerate(self.sizes):
             _lib.call("mireg_resize_bilinear_fwd", moving_ptr, self.moving_r[i].data_ptr(), B, 1, H, W, h, w,
@@ -121,7 +123,8 @@ class FusedRegLoss:
                   gamma, zeta, self.g4.data_ptr(), self.coef.data_ptr(), st)
         if self.fused:
             tab, blocks = self._table(flows)
-            _lib.call("mireg_tail_bwd", tab.data_ptr(), self.n, blocks, B, st)
+            PROFILER.call("tail_bwd", 28.0 * sum(B * h * w for h, w in self.sizes), "tail:bwd", "mireg_tail_bwd", tab.data_ptr(),
+                          self.n, blocks, B, st, unit="B")
             return self.gflow
         for i, (h, w) in enumerate(self.sizes):
             f = flows[i]
@@ -143,7 +146,7 @@ class RegistrationTrainer:
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-4,
                  lamb_da: float = 0.5, gamma: float = 100.0, zeta: float = 100.0, use_graph: bool = True,
                  process_group=None, sync_loss_stats: bool = False, overlap: bool = True, packed_optimizer: bool = True,
-                 autotune: bool = True):
+                 autotune: bool = True, tune_cache: Optional[str] = None):
         self.model = model
         self.predictor = model.predictor
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -159,6 +162,7 @@ class RegistrationTrainer:
         self._seg_ranges = [None]
         self.packed = packed_optimizer
         self.autotune = autotune
+        self.tune_cache = tune_cache        # JSON file of measured launch shapes: loaded if present, written after tuning
         self._packs_fresh = False
         self.flat_p = flatten_parameters(model)
         dev = self.flat_p.device
@@ -208,7 +212,13 @@ class RegistrationTrainer:
         B, _, H, W = x.shape
         self.loss = FusedRegLoss(B, H, W, sizes, x.device, *self.loss_hyper)
         if self.autotune:
-            self._autotune()
+            import os
+            if self.tune_cache and os.path.exists(self.tune_cache):
+                self.eng.ws.load_tuning(self.tune_cache)
+            else:
+                self._autotune()
+                if self.tune_cache:
+                    self.eng.ws.save_tuning(self.tune_cache)
 
     def refresh_packs(self) -> None:
         """Re-derive every GEMM pack from the fp32 master weights (after load_state_dict / manual edits)."""
@@ -278,8 +288,10 @@ class RegistrationTrainer:
                 jobs.append(j)
             self._wopt_tab = (upload_table(jobs, self.flat_p.device), len(jobs), units, max(j.taps for j in jobs))
         tab, n, units, max_taps = self._wopt_tab
-        _lib.call("mireg_adam_pack", tab.data_ptr(), n, units, max_taps, self.step_dev.data_ptr(), 0, self.lr, self.betas[0],
-                  self.betas[1], self.eps, 1.0 / self.world, self.eng.ws.code, st)
+        nparam = sum(l.weight.numel() for l in self.eng.layers.values() if l.wgrad_slab is not None)
+        PROFILER.call("adam_pack", 30.0 * nparam, "optimizer", "mireg_adam_pack", tab.data_ptr(), n, units, max_taps,
+                      self.step_dev.data_ptr(), 0, self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world,
+                      self.eng.ws.code, st, unit="B")
         self.eng.pack_weights(dgrad_only=True)
         self._packs_fresh = True
 
