@@ -234,8 +234,11 @@ int mireg_cast_to_f32(float* dst, long ld_d, const void* src, long ld_s, long M,
 /* x[:, c0:c0+nc] of an NCHW fp32 batch (train.py:44-46 hands NCHW) -> NHWC rows with pixel stride ld */
 int mireg_nchw_to_nhwc(const float* src, void* dst, int B, int Ctot, int c0, int nc, long HW, long ld, int dtype,
                        hipStream_t stream);
-/* bias gradients: out[c] (+)= sum_m g[m][c] */
-int mireg_colsum(const void* g, long ld, long M, int C, float* out, int accumulate, int dtype, hipStream_t stream);
+/* bias gradients: out[c] (+)= sum_m g[m][c], fixed summation order on the vector path (C % 8 == 0 for bf16 / % 4 fp32).
+ * workspace: MIREG_COLSUM_MAX_SEGMENTS * C floats, needed once M > 8192 (row segments + finalize); may be NULL. */
+#define MIREG_COLSUM_MAX_SEGMENTS 64
+int mireg_colsum(const void* g, long ld, long M, int C, float* out, int accumulate, float* workspace, int dtype,
+                 hipStream_t stream);
 
 /* ---- K20: Adam exactly as train.py:129 builds it (betas .9/.999, eps = lrMin = 1e-4) ---------- */
 typedef struct mireg_adam_job { float* p; const float* g; float* m; float* v; long n; } mireg_adam_job;

@@ -527,6 +527,56 @@ colsum_kernel(const T* __restrict__ g, long ld, long M, int C, float* __restrict
   if (threadIdx.x == 0) atomicAdd(&out[c], red[0]);
 }
 
+// bias gradient = column sums of dy, deterministic: block = 2 channel granules x one row segment (128 row lanes,
+// xor-tree + 4 waves in order); one segment writes `out` directly, several go through partial[seg][C] + a tiny finalize
+template <typename T>
+__global__ void __launch_bounds__(256)
+colsum_vec_kernel(const T* __restrict__ g, long ld, long M, int C, float* __restrict__ dst, int accumulate, long rows_per_seg) {
+  constexpr int V = VecOf<T>::N;
+  __shared__ float wsum[4][2][V];
+  const int gsel = threadIdx.x & 1, rl = threadIdx.x >> 1, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c0 = (blockIdx.x * 2 + gsel) * V;
+  const long m0 = (long)blockIdx.y * rows_per_seg, m1 = m0 + rows_per_seg < M ? m0 + rows_per_seg : M;
+  float a[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) a[v] = 0.f;
+  if (c0 < C) {
+#pragma unroll 4
+    for (long m = m0 + rl; m < m1; m += 128) {
+      float yv[V];
+      ldv(g + m * ld + c0, yv);
+#pragma unroll
+      for (int v = 0; v < V; ++v) a[v] += yv[v];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+#pragma unroll
+    for (int off = 2; off < 64; off <<= 1) a[v] += __shfl_xor(a[v], off, 64);
+  if (lane < 2) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) wsum[wid][lane][v] = a[v];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * V) {
+    const int gs = threadIdx.x / V, v = threadIdx.x % V, c = (blockIdx.x * 2 + gs) * V + v;
+    if (c < C) {
+      const float s = ((wsum[0][gs][v] + wsum[1][gs][v]) + wsum[2][gs][v]) + wsum[3][gs][v];
+      float* d = dst + (long)blockIdx.y * C + c;                       // gridDim.y == 1: dst = out, else partial[seg][C]
+      *d = (gridDim.y == 1 && accumulate) ? *d + s : s;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+colsum_finalize_kernel(const float* __restrict__ partial, int nseg, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nseg; ++k) s += partial[(long)k * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
 // fused multi-tensor Adam (torch.optim.Adam semantics, no weight decay / amsgrad); step lives on device so
 // the launch is hipGraph-replayable.  float4 streams: 28 B of traffic per parameter.
 __global__ void adam_tick_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
@@ -817,8 +867,25 @@ int mireg_nchw_to_nhwc(const float* src, void* dst, int B, int Ctot, int c0, int
   MIREG_LAUNCH_RET();
 }
 
-int mireg_colsum(const void* g, long ld, long M, int C, float* out, int accumulate, int dtype, hipStream_t stream) {
+int mireg_colsum(const void* g, long ld, long M, int C, float* out, int accumulate, float* workspace, int dtype,
+                 hipStream_t stream) {
   MIREG_CHECK_ARG(g && out && M > 0 && C > 0);
+  if (vec_ok(dtype, C, {ld}, {g})) {
+    const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4, gp = (C / V + 1) / 2;
+    int nseg = 1;
+    if (M > 8192 && workspace) {
+      nseg = (256 + gp - 1) / gp;
+      if (nseg > MIREG_COLSUM_MAX_SEGMENTS) nseg = MIREG_COLSUM_MAX_SEGMENTS;
+      if ((long)nseg * 2048 > M) nseg = (int)(M / 2048);
+      if (nseg < 1) nseg = 1;
+    }
+    const long rps = (M + nseg - 1) / nseg;
+    float* dst = nseg == 1 ? out : workspace;
+    if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((colsum_vec_kernel<__bf16>), dim3(gp, nseg), dim3(256), 0, stream, (const __bf16*)g, ld, M, C, dst, accumulate, rps);
+    else hipLaunchKernelGGL((colsum_vec_kernel<float>), dim3(gp, nseg), dim3(256), 0, stream, (const float*)g, ld, M, C, dst, accumulate, rps);
+    if (nseg > 1) hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, nseg, C, out, accumulate);
+    MIREG_LAUNCH_RET();
+  }
   if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, stream) != hipSuccess) return MIREG_ERR_LAUNCH;
   long gy = (M + 256 * 16 - 1) / (256 * 16);
   if (gy > 64) gy = 64;

@@ -168,6 +168,7 @@ class Workspace:
         self.scratch_elems = 0
         # launch-shape autotuning (tile width x split-K per contraction site): `tuning` is on during the trainer's
         # discarded tuning pass, `tuned` maps a launch site to its measured-best (tile_n, split_k)
+        self.colsum_ws: Optional[torch.Tensor] = None      # row-segment partials of the bias-gradient column sums
         self.tuning = False
         self.tuned: Dict[tuple, Tuple[int, int]] = {}
         self.tuned_wgrad: Dict[str, int] = {}              # layer name -> measured split-K of its backward-weights GEMM
@@ -568,7 +569,10 @@ class ConvLayer:
             return
         if self.grad_b is None:
             self.grad_b = torch.zeros_like(self.bias, dtype=F32)
-        _lib.call("mireg_colsum", dy.ptr, dy.ld, dy.rows, dy.C, self.grad_b.data_ptr(), int(accumulate), self.ws.code,
+        if self.ws.colsum_ws is None or self.ws.colsum_ws.numel() < 64 * dy.C:
+            self.ws.colsum_ws = torch.empty(64 * max(dy.C, 1024), device=self.ws.device, dtype=F32)
+        _lib.call("mireg_colsum", dy.ptr, dy.ld, dy.rows, dy.C, self.grad_b.data_ptr(), int(accumulate),
+                  self.ws.colsum_ws.data_ptr(), self.ws.code,
                   _stream())
 
 
