@@ -195,6 +195,25 @@ def main():
         except Exception as e:  # the quality leg must never break the timing line
             dice = {"error": repr(e)}
 
+    # ---- eval leg: forward + warps + OFEloss + warped-seg Dice per batch, eager, same weights ----------
+    ev_line = None
+    if rank == 0:
+        try:
+            xs, ss = x, seg_cpu.to(dev)
+            for _ in range(2):
+                trainer.evaluate(xs, ss)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_ev = 10
+            for _ in range(n_ev):
+                trainer.evaluate(xs, ss)
+            torch.cuda.synchronize()
+            t_ev = (time.perf_counter() - t0) / n_ev
+            ev_line = {"pairs_per_s": round(args.batch / t_ev, 1), "ms_per_batch": round(t_ev * 1e3, 3),
+                       "note": "inference.py:43-68 shaped: eval forward + stn + OFEloss + seg warp/round + per-sample Dice, 1 GPU, eager"}
+        except Exception as e:
+            ev_line = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.batch, args.size, args.cpu_steps, seed=6)
@@ -208,7 +227,7 @@ def main():
                                       f"{args.precision} operands fp32 accumulate, train step", "global_batch": args.batch * world,
                           "parallelism": f"dp{world}", "hipgraph": not args.no_graph},
                "loss": {"photo": loss_vals[0], "corr": loss_vals[1], "smooth": loss_vals[2], "total": loss_vals[3]},
-               "roofline": roof, "cpu_baseline": cpu, "dice": dice}
+               "roofline": roof, "cpu_baseline": cpu, "dice": dice, "eval": ev_line}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -592,6 +592,9 @@ class BatchNormAct:
 
     def forward(self, y: View, out: View, training: bool) -> None:
         bn = self.bn
+        if training and y.rows == 1:     # same refusal as torch.nn.functional.batch_norm (reference BatchNorm2d in train mode)
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([{y.B}, {self.C}, {y.H}, {y.W}])")
         mom = bn.momentum if bn.momentum is not None else 0.1
         _lib.call("mireg_bn_forward", y.ptr, y.ld, out.ptr, out.ld, y.rows, self.C, bn.weight.data_ptr(),
                   bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(mom), float(bn.eps),
