@@ -189,6 +189,104 @@ correlation_bwd_kernel(const T* __restrict__ g, long ldg, const T* __restrict__ 
   }
 }
 
+// bf16 cost-volume backward on the bf16 matrix cores.  Block = one (b, output row y, 32-pixel x tile); per valid
+// displacement row dyi the 4 waves cooperatively stage in LDS
+//   Bt[kk][c]  = the other feature map's row yy, pixels klo..klo+KW-1 (channel-contiguous, as in HBM), and
+//   At[m][kk]  = the banded displacement-gradient matrix (G gathered once per block, shared by all channel tiles);
+// A fragments are plain 16-byte LDS reads, B fragments come through the gfx950 transposing read ds_read_b64_tr_b16
+// (K = pixels is the strided dimension in memory), and every wave owns the 32-channel tiles j = wid, wid+4, ...
+// so one A fragment feeds all of a wave's MFMAs of a K-step.  Same sums as correlation_bwd_kernel, fp32 accumulate.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <int WHICH, int NTW>
+__global__ void __launch_bounds__(256)
+correlation_bwd_mfma_kernel(const __bf16* __restrict__ g, long ldg, const __bf16* __restrict__ fo, long ldo_, __bf16* __restrict__ dout,
+                            long ldd, int B, int H, int W, int C, int c_norm, int R, int s2, int accumulate, int KW, int LDB) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  __bf16* Bt = reinterpret_cast<__bf16*>(dyn);                    // [KW][LDB]
+  __bf16* At = Bt + (long)KW * LDB;                               // [32][KW + 8]
+  const int LDA = KW + 8;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int D = 2 * R + 1;
+  const int xt = (W + 31) / 32;
+  const int u = blockIdx.x;
+  const int x0 = (u % xt) * 32, y = (u / xt) % H, b = u / (xt * H);
+  const int klo = max(0, x0 - R * s2) & ~15;                      // first staged pixel of the other map (16-aligned)
+  const int nsteps = KW / 16;
+  const int ntiles = (C + 31) / 32;
+  const float inv_c = 1.f / (float)c_norm;
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  // transposing-read geometry (see conv_wgrad_kernel): 16-lane group gq covers columns 16*(gq&1).., rows 8*(gq>>1)+q(+4)
+  const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int rowoff = 8 * (gq >> 1) + q, coloff = 16 * (gq & 1) + 4 * pp;
+  const int cgran = LDB / 8;                                       // 16-byte granules per staged row (incl. zero pad columns)
+
+  for (int dyi = 0; dyi < D; ++dyi) {
+    const int yy = WHICH == 0 ? y + (dyi - R) * s2 : y - (dyi - R) * s2;          // row of the other feature map
+    if (yy < 0 || yy >= H) continue;                                              // block-uniform
+    __syncthreads();                                                              // previous row's fragments are consumed
+    // ---- stage the feature row: 16-byte loads, zero rows / columns outside the image or past C -------------------
+    const __bf16* frow = fo + (((long)b * H + yy) * W) * ldo_;
+    for (int e = threadIdx.x; e < KW * cgran; e += 256) {
+      const int kk = e / cgran, cg = e - kk * cgran;
+      const int k = klo + kk;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (k < W && cg * 8 < C) v = *GPTR(const uint4, frow + (long)k * ldo_ + cg * 8);
+      *reinterpret_cast<uint4*>(Bt + (long)kk * LDB + cg * 8) = v;
+    }
+    // ---- stage the band: At[m][kk] = G[.., dyi*D + dxi] where pixel k = klo + kk pairs with output pixel x0 + m ----
+    const int gy = WHICH == 0 ? y : yy;
+    for (int e = threadIdx.x; e < 32 * KW; e += 256) {
+      const int m = e / KW, kk = e - m * KW;
+      const int xm = x0 + m, k = klo + kk;
+      __bf16 v = (__bf16)0.f;
+      if (xm < W && k < W) {
+        const int diff = WHICH == 0 ? k - xm : xm - k;                            // s2 * (dxi - R)
+        const int dq = diff / s2;
+        if (dq * s2 == diff && dq >= -R && dq <= R) {
+          const int gx = WHICH == 0 ? xm : k;
+          v = *GPTR(const __bf16, g + (((long)b * H + gy) * W + gx) * ldg + dyi * D + dq + R);
+        }
+      }
+      At[m * LDA + kk] = v;
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nsteps; ++ks) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + r * LDA + ks * 16 + 8 * h);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int tile = wid + 4 * j;
+        if (tile < ntiles) {                                                      // wave-uniform
+          const __bf16* base = Bt + (long)(ks * 16 + rowoff) * LDB + tile * 32 + coloff;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + 4 * LDB));
+          const __attribute__((ext_vector_type(8))) short v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, v), acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int c = (wid + 4 * j) * 32 + r;
+    if (wid + 4 * j >= ntiles || c >= C) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int xo = x0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (xo >= W) continue;
+      __bf16* d = dout + (((long)b * H + y) * W + xo) * ldd + c;
+      float v = acc[j][e] * inv_c;
+      if (accumulate) v += ldf(d);
+      stf(d, v);
+    }
+  }
+}
+
 // PWCDCNet.warp (PWC/models/PWCNet.py:143-179): grid normalised with (W-1) but sampled with align_corners=False,
 // so the tap coordinate is ((2(x+u)/(W-1) - 1 + 1) * W - 1) / 2; output * (bilinear(ones) >= 0.9999).
 template <typename T>
@@ -357,6 +455,25 @@ int mireg_correlation_bwd(const void* g, long ldg, const void* f1, long ld1, con
   long gr = (units + 3) / 4;
   if (gr > 4096) gr = 4096;
   const int R = max_displacement / stride2;
+  // bf16 with 16-byte aligned channel rows: bf16 matrix cores + LDS-staged operands
+  if (dtype == MIREG_DTYPE_BF16 && C <= 512 && C % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && (uintptr_t)f1 % 16 == 0 && (uintptr_t)f2 % 16 == 0 &&
+      (uintptr_t)g % 2 == 0 && units < (1L << 30)) {
+    const int span = 32 + 2 * R * stride2 + 15;                                  // pixels a tile can pair with, from a 16-aligned start
+    const int KW = (span + 15) / 16 * 16;
+    const int LDB = (C + 31) / 32 * 32 + 8;
+    const size_t lds = ((size_t)KW * LDB + 32 * (KW + 8)) * 2;
+    const int ntw = ((C + 31) / 32 + 3) / 4;
+    if (lds <= 150 * 1024) {
+#define MIREG_CORR_BWD(WHICH, NTW, gp, fo_, ldo__, dd, lddd, acc_) { \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)correlation_bwd_mfma_kernel<WHICH, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((correlation_bwd_mfma_kernel<WHICH, NTW>), dim3((unsigned)units), dim3(256), lds, stream, (const __bf16*)gp, ldg, \
+                           (const __bf16*)fo_, ldo__, (__bf16*)dd, lddd, B, H, W, C, c_norm, R, stride2, acc_, KW, LDB); }
+      if (df1) { if (ntw <= 1) MIREG_CORR_BWD(0, 1, g, f2, ld2, df1, ldd1, accumulate1) else if (ntw == 2) MIREG_CORR_BWD(0, 2, g, f2, ld2, df1, ldd1, accumulate1) else MIREG_CORR_BWD(0, 4, g, f2, ld2, df1, ldd1, accumulate1) }
+      if (df2) { if (ntw <= 1) MIREG_CORR_BWD(1, 1, g, f1, ld1, df2, ldd2, accumulate2) else if (ntw == 2) MIREG_CORR_BWD(1, 2, g, f1, ld1, df2, ldd2, accumulate2) else MIREG_CORR_BWD(1, 4, g, f1, ld1, df2, ldd2, accumulate2) }
+#undef MIREG_CORR_BWD
+      MIREG_LAUNCH_RET();
+    }
+  }
   if (dtype == MIREG_DTYPE_BF16) {
     if (df1) hipLaunchKernelGGL((correlation_bwd_kernel<__bf16, 0>), dim3((unsigned)gr), dim3(256), 0, stream, (const __bf16*)g, ldg, (const __bf16*)f2, ld2, (__bf16*)df1, ldd1, B, H, W, C, c_norm, R, stride2, accumulate1);
     if (df2) hipLaunchKernelGGL((correlation_bwd_kernel<__bf16, 1>), dim3((unsigned)gr), dim3(256), 0, stream, (const __bf16*)g, ldg, (const __bf16*)f1, ld1, (__bf16*)df2, ldd2, B, H, W, C, c_norm, R, stride2, accumulate2);
