@@ -226,36 +226,58 @@ correlation_bwd_mfma_kernel(const __bf16* __restrict__ g, long ldg, const __bf16
   const int rowoff = 8 * (gq >> 1) + q, coloff = 16 * (gq & 1) + 4 * pp;
   const int cgran = LDB / 8;                                       // 16-byte granules per staged row (incl. zero pad columns)
 
-  for (int dyi = 0; dyi < D; ++dyi) {
-    const int yy = WHICH == 0 ? y + (dyi - R) * s2 : y - (dyi - R) * s2;          // row of the other feature map
-    if (yy < 0 || yy >= H) continue;                                              // block-uniform
-    __syncthreads();                                                              // previous row's fragments are consumed
-    // ---- stage the feature row: 16-byte loads, zero rows / columns outside the image or past C -------------------
+  // The band's nonzero pattern (which (m, kk) pair up) does not depend on dyi: zero the tile once, rewrite only the band.
+  for (int e = threadIdx.x; e < 32 * LDA; e += 256) At[e] = (__bf16)0.f;
+  constexpr int NB = 14, NA = 4;                                   // register staging: 256 * NB granules >= KW * cgran, 256 * NA >= 32 * D
+  uint4 breg[NB];
+  __bf16 areg[NA];
+  auto fetch = [&](int dyi) {                                      // global loads only (branch-free), consumed one iteration later
+    const int yy = WHICH == 0 ? y + (dyi - R) * s2 : y - (dyi - R) * s2;
     const __bf16* frow = fo + (((long)b * H + yy) * W) * ldo_;
-    for (int e = threadIdx.x; e < KW * cgran; e += 256) {
-      const int kk = e / cgran, cg = e - kk * cgran;
-      const int k = klo + kk;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (k < W && cg * 8 < C) v = *GPTR(const uint4, frow + (long)k * ldo_ + cg * 8);
-      *reinterpret_cast<uint4*>(Bt + (long)kk * LDB + cg * 8) = v;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      const int kk = e / cgran, cg = e - kk * cgran, k = klo + kk;
+      const bool ok = e < KW * cgran && k < W && cg * 8 < C;
+      const uint4 v = *GPTR(const uint4, frow + (long)(ok ? k : 0) * ldo_ + (ok ? cg * 8 : 0));
+      breg[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
     }
-    // ---- stage the band: At[m][kk] = G[.., dyi*D + dxi] where pixel k = klo + kk pairs with output pixel x0 + m ----
     const int gy = WHICH == 0 ? y : yy;
-    for (int e = threadIdx.x; e < 32 * KW; e += 256) {
-      const int m = e / KW, kk = e - m * KW;
-      const int xm = x0 + m, k = klo + kk;
-      __bf16 v = (__bf16)0.f;
-      if (xm < W && k < W) {
-        const int diff = WHICH == 0 ? k - xm : xm - k;                            // s2 * (dxi - R)
-        const int dq = diff / s2;
-        if (dq * s2 == diff && dq >= -R && dq <= R) {
-          const int gx = WHICH == 0 ? xm : k;
-          v = *GPTR(const __bf16, g + (((long)b * H + gy) * W + gx) * ldg + dyi * D + dq + R);
-        }
-      }
-      At[m * LDA + kk] = v;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      const int m = e / D, dxi = e - m * D, xm = x0 + m;
+      const int k = WHICH == 0 ? xm + (dxi - R) * s2 : xm - (dxi - R) * s2;     // the other map's pixel this entry pairs with
+      const bool ok = e < 32 * D && xm < W && k >= 0 && k < W;
+      const int gx = WHICH == 0 ? xm : k;
+      const __bf16 v = *GPTR(const __bf16, g + (((long)b * H + gy) * W + (ok ? gx : 0)) * ldg + (ok ? dyi * D + dxi : 0));
+      areg[i] = ok ? v : (__bf16)0.f;
     }
+  };
+  auto commit = [&]() {                                            // registers -> LDS tiles
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      if (e < KW * cgran) { const int kk = e / cgran, cg = e - kk * cgran; *reinterpret_cast<uint4*>(Bt + (long)kk * LDB + cg * 8) = breg[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      const int m = e / D, dxi = e - m * D, xm = x0 + m;
+      const int k = WHICH == 0 ? xm + (dxi - R) * s2 : xm - (dxi - R) * s2;
+      if (e < 32 * D && k >= klo && k < klo + KW) At[m * LDA + (k - klo)] = areg[i];
+    }
+  };
+  // valid displacement rows form one interval [d_lo, d_hi]
+  int d_lo = 0, d_hi = D - 1;
+  while (d_lo < D) { const int yy = WHICH == 0 ? y + (d_lo - R) * s2 : y - (d_lo - R) * s2; if (yy >= 0 && yy < H) break; ++d_lo; }
+  while (d_hi >= 0) { const int yy = WHICH == 0 ? y + (d_hi - R) * s2 : y - (d_hi - R) * s2; if (yy >= 0 && yy < H) break; --d_hi; }
+  if (d_lo <= d_hi) fetch(d_lo);
+  for (int dyi = d_lo; dyi <= d_hi; ++dyi) {
+    __syncthreads();                                               // previous row's fragments are consumed (and the zero fill landed)
+    commit();
     __syncthreads();
+    if (dyi < d_hi) fetch(dyi + 1);                                // next row's loads fly under this row's MFMAs
     for (int ks = 0; ks < nsteps; ++ks) {
       const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + r * LDA + ks * 16 + 8 * h);
 #pragma unroll
@@ -463,7 +485,7 @@ int mireg_correlation_bwd(const void* g, long ldg, const void* f1, long ld1, con
     const int LDB = (C + 31) / 32 * 32 + 8;
     const size_t lds = ((size_t)KW * LDB + 32 * (KW + 8)) * 2;
     const int ntw = ((C + 31) / 32 + 3) / 4;
-    if (lds <= 150 * 1024) {
+    if (lds <= 150 * 1024 && (long)KW * (LDB / 8) <= 256 * 14 && 32 * (2 * R + 1) <= 256 * 4) {
 #define MIREG_CORR_BWD(WHICH, NTW, gp, fo_, ldo__, dd, lddd, acc_) { \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)correlation_bwd_mfma_kernel<WHICH, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((correlation_bwd_mfma_kernel<WHICH, NTW>), dim3((unsigned)units), dim3(256), lds, stream, (const __bf16*)gp, ldg, \
