@@ -30,6 +30,17 @@ __device__ __forceinline__ float ldf(const float* p) { return *GPTR(const float,
 __device__ __forceinline__ float ldf(const __bf16* p) { return (float)*GPTR(const __bf16, p); }
 __device__ __forceinline__ void stf(float* p, float v) { *GPTR(float, p) = v; }
 __device__ __forceinline__ void stf(__bf16* p, float v) { *GPTR(__bf16, p) = (__bf16)v; }
+// one 16-byte channel granule -> floats
+__device__ __forceinline__ void ld_granule(const float* p, float (&v)[4]) {
+  const float4 q = *GPTR(const float4, p);
+  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+__device__ __forceinline__ void ld_granule(const __bf16* p, float (&v)[8]) {
+  const uint4 q = *GPTR(const uint4, p);
+  const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
 
 // one block = one (b, y, 32-pixel x tile): its 4 waves split the D displacement rows, every wave turns a
 // (dy, x' tile) into one 32x32xC MFMA product and drops the band into the block's LDS output tile [32 px][D*D];
@@ -362,8 +373,10 @@ pwc_warp_bwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__
   constexpr int V = 16 / (int)sizeof(T);
   const int cpr = C / V;
   const long total = (long)B * H * W * cpr;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i0 = (long)blockIdx.x * blockDim.x; i0 < total; i0 += (long)gridDim.x * blockDim.x) {   // wave-uniform trip count
 #pragma clang fp contract(off)
+    const bool active = i0 + threadIdx.x < total;
+    const long i = active ? i0 + threadIdx.x : total - 1;
     const long pix = i / cpr;
     const int c0 = (int)(i - pix * cpr) * V;
     const int xq = (int)(pix % W), yq = (int)((pix / W) % H);
@@ -381,28 +394,41 @@ pwc_warp_bwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__
       const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
       if (xi >= 0 && xi < W && yi >= 0 && yi < H) msk += ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
     }
-    if (msk < 0.9999f) continue;                         // masked pixel: no gradient at all
+    const bool live = active && msk >= 0.9999f;          // masked pixel: no gradient at all
     float gv[V];
-#pragma unroll
-    for (int q = 0; q < V; ++q) gv[q] = ldf(g + pix * ldg + c0 + q);
+    ld_granule(g + pix * ldg + c0, gv);
     float dpx = 0.f, dpy = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
-      if (xi < 0 || xi >= W || yi < 0 || yi >= H) continue;
+      if (!live || xi < 0 || xi >= W || yi < 0 || yi >= H) continue;
       const float wx = (t & 1) ? wx1 : wx0, wy = (t >> 1) ? wy1 : wy0;
       const float dwx = (t & 1) ? 1.f : -1.f, dwy = (t >> 1) ? 1.f : -1.f;
       const long tp = ((img * H + yi) * W + xi);
+      float xv[V];
+      ld_granule(x + tp * ldx + c0, xv);
 #pragma unroll
       for (int q = 0; q < V; ++q) {
-        const float xv = ldf(x + tp * ldx + c0 + q);
         atomicAdd(dx32 + tp * lddx + c0 + q, gv[q] * wx * wy);
-        dpx += gv[q] * xv * dwx * wy;
-        dpy += gv[q] * xv * wx * dwy;
+        dpx += gv[q] * xv[q] * dwx * wy;
+        dpy += gv[q] * xv[q] * wx * dwy;
       }
     }
-    atomicAdd(dflow + pix * lddf, dpx * flow_scale * (float)W / (float)max(W - 1, 1));
-    atomicAdd(dflow + pix * lddf + 1, dpy * flow_scale * (float)H / (float)max(H - 1, 1));
+    // the channel granules of one pixel sit in consecutive lanes: segmented shuffle reduction, then ONE atomic pair per
+    // pixel and wave instead of one per granule (they all hit the same two addresses)
+    const int lane = threadIdx.x & 63;
+    long key = active ? pix : -1 - (long)threadIdx.x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float ox = __shfl_down(dpx, off, 64), oy = __shfl_down(dpy, off, 64);
+      const long ok_ = __shfl_down(key, off, 64);
+      if (lane + off < 64 && ok_ == key) { dpx += ox; dpy += oy; }
+    }
+    const long prev = __shfl_up(key, 1, 64);
+    if (live && (lane == 0 || prev != key)) {
+      atomicAdd(dflow + pix * lddf, dpx * flow_scale * (float)W / (float)max(W - 1, 1));
+      atomicAdd(dflow + pix * lddf + 1, dpy * flow_scale * (float)H / (float)max(H - 1, 1));
+    }
   }
 }
 
@@ -426,7 +452,7 @@ int mireg_pwc_warp_bwd(const void* x, long ldx, const float* flow, long ldf_, fl
                        float* dx32, long lddx, float* dflow, long lddf, int B, int H, int W, int C, int dtype, hipStream_t stream) {
   MIREG_CHECK_ARG(x && flow && g && dx32 && dflow && B > 0 && H > 0 && W > 0 && C > 0 && ldf_ >= 2 && lddf >= 2);
   const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
-  MIREG_CHECK_ARG(C % V == 0);
+  MIREG_CHECK_ARG(C % V == 0 && ldx % V == 0 && ldg % V == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)g % 16 == 0);
   const long total = (long)B * H * W * (C / V);
   long gr = (total + 255) / 256;
   if (gr > 4096) gr = 4096;
