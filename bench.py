@@ -95,11 +95,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
+    local = local % max(torch.cuda.device_count(), 1)            # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MIREG_DIST_BACKEND", "nccl")      # "gloo" only to rehearse the N>1 logic on one GPU
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     import mireg
     from mireg.engine import PROFILER
