@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-for shape in "fwd 256 256 3 1 32 24" "fwd 128 256 5 2 64 24" "dgrad 256 256 3 1 32 24" "fwd 512 512 3 1 16 24" ; do
+for shape in "wgrad 256 256 3 1 32 24" "wgrad 128 256 5 2 64 24" "wgrad 512 512 3 1 16 24" "wgrad 64 128 5 2 128 24"; do
   for v in "" NOISSUE NOCOMPUTE; do
     if [ -z "$v" ]; then unset MIREG_LIB; else export MIREG_LIB=$R/scratch/libmireg_$v.so; fi
     echo -n "[$v] "; python3 $R/scratch/mb_conv.py $shape bf16 20 2>/dev/null | tail -1

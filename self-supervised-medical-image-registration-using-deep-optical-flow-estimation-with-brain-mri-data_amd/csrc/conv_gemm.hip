@@ -707,18 +707,30 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   const int b_ty = b_tap / p.taps_x, b_tx = b_tap - b_ty * p.taps_x;
   const int b_dy = p.off_y + b_ty * p.step_y, b_dx = p.off_x + b_tx * p.step_x;
 
-  // this lane's pixel for its two DMA instructions, kept decomposed (img, gy, gx) and advanced by BK per K-step
-  int pix[2], p_img[2], p_gy[2], p_gx[2];
+  // this lane's pixel for its two DMA instructions, kept decomposed (img, gy, gx) and advanced by BK per K-step.
+  // Everything the DMA needs is a running 32-bit quantity (buffer offsets are 32-bit; x_bytes, w_bytes < 2^31):
+  // byte offsets of the pixel in dy and of its tap-shifted source pixel in x, plus the source coordinates for the
+  // zero-padding test, all updated with adds on the carries -- no multiplies in the steady state.
+  const unsigned sz = (unsigned)sizeof(T);
+  const unsigned PIXB = (unsigned)p.x_ld * sz;                                    // one source pixel
+  const unsigned STEPX = (unsigned)p.mul_x * PIXB, ROWB_X = (unsigned)p.x_W * PIXB, STEPY = (unsigned)p.mul_y * ROWB_X;
+  const unsigned IMGB = (unsigned)p.x_H * ROWB_X;
+  const unsigned y_ldb = (unsigned)p.y_ld * sz;
+  int pix[2], p_gy[2], p_gx[2], s_iy[2], s_ix[2];
+  unsigned a_off[2], b_off[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     pix[c] = kt_begin * BK + (wid + 4 * c) * RPI + lrow;
     const int pp = min(pix[c], P - 1);
-    p_img[c] = pp / gHW;
-    const int rem = pp - p_img[c] * gHW;
+    const int img = pp / gHW;
+    const int rem = pp - img * gHW;
     p_gy[c] = rem / p.g_W;
     p_gx[c] = rem - p_gy[c] * p.g_W + (pix[c] - pp);            // a tail overshoot stays on the x axis (never used: pok)
+    s_iy[c] = p_gy[c] * p.mul_y + b_dy;
+    s_ix[c] = p_gx[c] * p.mul_x + b_dx;
+    a_off[c] = (unsigned)pix[c] * y_ldb + (unsigned)a_col * sz;
+    b_off[c] = (unsigned)img * IMGB + (unsigned)(s_iy[c] * (int)ROWB_X) + (unsigned)(s_ix[c] * (int)PIXB) + (unsigned)b_ch * sz;
   }
-  const long y_ldb = p.y_ld * (long)sizeof(T);
 
   auto issue = [&](int stage) {
     unsigned char* At = smem + stage * STAGE_BYTES;
@@ -726,18 +738,25 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const bool pok = pix[c] < P;
-      const unsigned aoff = (pok && a_cok) ? (unsigned)((long)pix[c] * y_ldb + a_col * (long)sizeof(T)) : kOOB;
+      const unsigned aoff = (pok && a_cok) ? a_off[c] : kOOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_void_t)(At + (wid + 4 * c) * 1024), 16, aoff, 0, 0, 0);
-      unsigned boff = kOOB;
-      const int iy = p_gy[c] * p.mul_y + b_dy, ix = p_gx[c] * p.mul_x + b_dx;
-      if (pok && b_cok && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W)
-        boff = (unsigned)(((((long)p_img[c] * p.x_H + iy) * p.x_W + ix) * p.x_ld + b_ch) * (long)sizeof(T));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t)(Bt + (wid + 4 * c) * 1024), 16, boff, 0, 0, 0);
+      const bool bok = pok && b_cok && (unsigned)s_iy[c] < (unsigned)p.x_H && (unsigned)s_ix[c] < (unsigned)p.x_W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t)(Bt + (wid + 4 * c) * 1024), 16, bok ? b_off[c] : kOOB, 0, 0, 0);
       pix[c] += BK;
+      a_off[c] += BK * y_ldb;
       p_gx[c] += BK;
+      s_ix[c] += BK * p.mul_x;
+      b_off[c] += BK * STEPX;
       while (p_gx[c] >= p.g_W) {                                    // carry into rows / images
         p_gx[c] -= p.g_W;
-        if (++p_gy[c] == p.g_H) { p_gy[c] = 0; ++p_img[c]; }
+        s_ix[c] -= p.g_W * p.mul_x;
+        b_off[c] += STEPY - (unsigned)p.g_W * STEPX;
+        s_iy[c] += p.mul_y;
+        if (++p_gy[c] == p.g_H) {
+          p_gy[c] = 0;
+          s_iy[c] -= p.g_H * p.mul_y;
+          b_off[c] += IMGB - (unsigned)p.g_H * STEPY;
+        }
       }
     }
   };
@@ -813,8 +832,12 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
     wait_vmcnt<8>();                                               // 2 younger tiles x 4 DMAs stay in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifndef MIREG_ABL_NOISSUE
     issue((it + STAGES - 1) % STAGES);
+#endif
+#ifndef MIREG_ABL_NOCOMPUTE
     compute(it % STAGES);
+#endif
   }
   for (; it < nk; ++it) {
     wait_vmcnt_dyn(min(STAGES - 2, nk - 1 - it) * 4);
