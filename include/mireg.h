@@ -191,6 +191,17 @@ int mireg_thin_conv_wgrad_tiles(int B, int H, int W, int Cpad, int dtype, int* p
 int mireg_thin_conv_wgrad(const void* x, long ld_x, const void* dy, long ld_dy, float* slab, int ntiles, int B, int H,
                           int W, int Cpad, int dtype, hipStream_t stream);
 
+/* ---- 7x7 / stride 2 / pad 3 input convolutions with 1 or 2 input channels and 64 outputs, bf16 (FlowNetS conv1
+ * `FlowNetS/FlowNetS.py:18`, FlowNetC's siamese conv1 `flownet2/networks/FlowNetC.py:20`): K re-ordered to (ky, kx, ci)
+ * so the input patch is staged once per 8x16 output tile.  x = NHWC bf16 input (channels 0..Ci-1 real), w = the
+ * standard FWD pack [64][49*Cpad], y / dy = NHWC bf16 [..][64]; wgrad writes mireg_stem_conv_blocks(B,H,W) partial
+ * slabs [blk][64][ld_w] in the standard layout (pad slots are never written: hand in zeroed memory). */
+int mireg_stem_conv_blocks(int B, int H, int W);
+int mireg_stem_conv_fwd(const void* x, long ld_x, const void* w, long ld_w, int Cpad, const float* bias, float slope,
+                        void* y, long ld_y, int B, int H, int W, int Ci, int Co, hipStream_t stream);
+int mireg_stem_conv_wgrad(const void* x, long ld_x, const void* dy, long ld_dy, float* slab, long ld_w, int Cpad,
+                          int nblocks, int B, int H, int W, int Ci, int Co, hipStream_t stream);
+
 /* ---- packed-domain optimizer for the convolution weights (train.py:55-57,129 zero_grad/backward/step) ----
  * The torch-layout gradient is never materialised on the training path:
  *   mireg_wgrad_reduce : g[co][k] = sum_{z<nsplit} slab[z][co][k]       (fixed order; jobs with nsplit == 0 own no units)

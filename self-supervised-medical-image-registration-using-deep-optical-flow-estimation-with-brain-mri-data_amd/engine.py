@@ -201,6 +201,7 @@ NUM_CU = 256
 
 
 FORCE_TILE_N = int(os.environ.get('MIREG_TILE_N', '0'))   # experiments only
+USE_STEM = True
 USE_THIN = True     # module switch (tests compare the thin kernels with the GEMM path)
 
 
@@ -290,6 +291,9 @@ class ConvLayer:
         self.grad_b: Optional[torch.Tensor] = None
         # two-channel 3x3 heads (predict_flow): vector-ALU streaming kernels instead of a 2-column GEMM
         self.thin = USE_THIN and (self.Co, self.kh, self.kw, self.s, self.p, self.d) == (2, 3, 3, 1, 1, 1)
+        # 1-2 channel 7x7/s2 input convolutions: patch-staged kernels with K = (ky, kx, ci) (stem_conv.hip)
+        self.stem = (USE_STEM and ws.code == DT_BF16 and (self.kh, self.kw, self.s, self.p, self.d) == (7, 7, 2, 3, 1)
+                     and self.Ci <= 2 and self.Co == 64)
         self.gpack: Optional[torch.Tensor] = None       # packed-domain gradient [Co][Kf] (view of the trainer's flat buffer)
 
     # ---- pack jobs ----------------------------------------------------------------------------
@@ -392,6 +396,12 @@ class ConvLayer:
         Wo = (x.W + 2 * self.p - self.d * (self.kw - 1) - 1) // self.s + 1
         out = y if y is not None else y32
         assert (out.H, out.W) == (Ho, Wo), (self.name, (out.H, out.W), (Ho, Wo))
+        if self.stem and y is not None and y32 is None and not accumulate:
+            PROFILER.call("stem_conv_fwd", 2.0 * x.B * Ho * Wo * self.Co * 49 * self.Ci, f"{self.name}:stem-fwd",
+                          "mireg_stem_conv_fwd", x.ptr, x.ld, self.packF.data_ptr(), self.Kf, self.Cip,
+                          self.bias.data_ptr() if (bias and self.bias is not None) else None, slope, y.ptr, y.ld,
+                          x.B, x.H, x.W, self.Ci, self.Co, _stream())
+            return
         if self.thin and slope == 1.0 and not accumulate:
             PROFILER.call("thin_conv_fwd", 2.0 * x.B * Ho * Wo * 2 * 9 * self.Ci, f"{self.name}:thin-fwd",
                           "mireg_thin_conv_fwd", x.ptr, x.ld, self.packF.data_ptr(), self.Kf,
@@ -485,6 +495,8 @@ class ConvLayer:
         nk = (dy.rows + bk - 1) // bk
         if self.thin:
             self.wgrad_split = _lib.lib().mireg_thin_conv_wgrad_tiles(dy.B, dy.H, dy.W, self.Cip, self.ws.code, None)
+        elif self.stem:
+            self.wgrad_split = _lib.lib().mireg_stem_conv_blocks(x.B, x.H, x.W)
         elif self.name in self.ws.tuned_wgrad:
             self.wgrad_split, self._wgrad_tuned = self.ws.tuned_wgrad[self.name], True
         else:
@@ -556,6 +568,11 @@ class ConvLayer:
                           "mireg_thin_conv_wgrad", x.ptr, x.ld, dy.ptr, dy.ld,
                           self.wgrad_slab[slot * self.wgrad_split].data_ptr(), self.wgrad_split, dy.B, dy.H, dy.W,
                           self.Cip, self.ws.code, _stream())
+            return
+        if self.stem:
+            PROFILER.call("stem_conv_wgrad", 2.0 * dy.rows * self.Co * 49 * self.Ci, f"{self.name}:stem-wgrad",
+                          "mireg_stem_conv_wgrad", x.ptr, x.ld, dy.ptr, dy.ld, self.wgrad_slab[slot * self.wgrad_split].data_ptr(),
+                          self.Kf, self.Cip, self.wgrad_split, x.B, x.H, x.W, self.Ci, self.Co, _stream())
             return
         if self.ws.tuning and not getattr(self, "_wgrad_tuned", False):
             self._tune_wgrad(x, dy)

@@ -39,6 +39,8 @@ CASES = [  # cin, cout, k, stride, pad, dil, H, W, B, bias
     (16, 16, 3, 2, 1, 1, 30, 26, 2, True),      # odd sizes, stride 2
     (1026, 2, 3, 1, 1, 1, 6, 6, 2, True),       # predict_flow head, wave-per-pixel thin kernels
     (34, 2, 3, 1, 1, 1, 96, 100, 2, True),      # predict_flow head, 8-lanes-per-pixel thin kernels (>= 16k pixels)
+    (2, 64, 7, 2, 3, 1, 64, 96, 3, True),       # FlowNetS stem (patch-staged kernels in bf16)
+    (1, 64, 7, 2, 3, 1, 40, 36, 2, False),      # FlowNetC stem, ragged tiles
 ]
 
 
