@@ -310,6 +310,12 @@ class RegistrationTrainer:
     def step(self, x: torch.Tensor) -> torch.Tensor:
         """One optimizer step on batch x (B,2,H,W) fp32 on device.  Returns the device tensor
         (photo, corr, smooth, total) in float64 WITHOUT synchronising (call .tolist() when needed)."""
+        if not x.is_cuda:
+            raise RuntimeError("RegistrationTrainer.step needs a device batch (there is no CPU path)")
+        if self.eng is not None and tuple(x.shape) != tuple(self.x_static.shape):
+            # e.g. the short last batch of an epoch: rebuild the per-shape state (engine buffers, tables, graphs)
+            torch.cuda.synchronize()
+            self.eng, self._graphs, self._graph_opt, self._warm, self._packs_fresh = None, None, None, 0, False
         if self.eng is None:
             self._setup(x)
         self.x_static.copy_(x)

@@ -116,3 +116,25 @@ def test_trainer_rejects_cpu_batches_and_refreshes_packs_after_load_state_dict()
     tr2.step(xd)
     l1_ref = tr2.step(xd).tolist()
     assert abs(l1[3] - l1_ref[3]) <= 2e-2 * abs(l1_ref[3]), (l0, l1, l1_ref)
+
+
+def test_trainer_survives_a_short_last_batch():
+    """train.py's DataLoader has no drop_last: the final batch of an epoch is smaller.  The trainer rebuilds its
+    per-shape state and keeps the optimizer state; losses stay finite and the weights keep moving."""
+    import mireg
+    from mireg.synth import make_pairs
+    torch.manual_seed(1)
+    m = mireg.opticalFlowReg("flownets", precision="bf16")
+    nets.analytic_weights_(m)
+    m = m.to(DEV)
+    x, _ = make_pairs(6, 64, seed=3)
+    xd = x.to(DEV)
+    tr = mireg.RegistrationTrainer(m, use_graph=True, autotune=False)
+    for _ in range(4):
+        la = tr.step(xd[:4]).tolist()
+    w0 = tr.flat_p.clone()
+    lb = tr.step(xd[4:6]).tolist()                           # batch of 2 after batches of 4
+    lc = tr.step(xd[:4]).tolist()
+    assert all(v == v and abs(v) < 1e9 for v in la + lb + lc)
+    assert (tr.flat_p - w0).abs().max().item() > 0
+    assert int(tr.step_dev.item()) == 6
