@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-3d", action="store_true", help="skip the 128^3 affmodel leg")
     ap.add_argument("--tune-cache", default=None, help="JSON of measured launch shapes (written after tuning, reused when present)")
     ap.add_argument("--no-autotune", action="store_true", help="heuristic launch shapes (counter-collection runs: the tuning pass is slow there)")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -219,6 +220,33 @@ def main():
         except Exception as e:
             ev_line = {"error": repr(e)}
 
+    # ---- 3-D leg (north_star "128^3 volumes"): the reference's only 3-D model, affmodel (models.py:156-191), forward +
+    # affine grid / trilinear sampling + Affloss on synthetic 128^3 pairs, B = 8 (BASELINE configs[4] batch) ----------------
+    vol_line = None
+    if rank == 0 and not args.no_3d:
+        try:
+            g = torch.Generator(device="cpu").manual_seed(6)
+            low = torch.rand(8, 2, 8, 8, 8, generator=g)
+            vol = torch.nn.functional.interpolate(low, size=(128, 128, 128), mode="trilinear", align_corners=False).to(dev)
+            aff = mireg.affmodel(fc_in=512 * 2 * 2 * 8, precision=args.precision).to(dev).eval()
+            with torch.no_grad():
+                for _ in range(2):
+                    para, wv = aff(vol)
+                    mireg.Affloss(wv, vol[:, 0:1])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n3 = 5
+                for _ in range(n3):
+                    para, wv = aff(vol)
+                    l3 = mireg.Affloss(wv, vol[:, 0:1])
+                torch.cuda.synchronize()
+            t3 = (time.perf_counter() - t0) / n3
+            vol_line = {"volumes_per_s": round(8 / t3, 1), "ms_per_batch": round(t3 * 1e3, 3), "batch": 8, "size": "128x128x128",
+                        "loss": float(l3[2]), "note": "affmodel forward (6 Conv3d+ReLU on the depth-enabled GEMM, Linear, fused affine-grid "
+                        "trilinear sampler) + Affloss, eager, 1 GPU; forward / evaluation only (no 3-D backward kernels yet)"}
+        except Exception as e:
+            vol_line = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.batch, args.size, args.cpu_steps, seed=6)
@@ -232,7 +260,7 @@ def main():
                                       f"{args.precision} operands fp32 accumulate, train step", "global_batch": args.batch * world,
                           "parallelism": f"dp{world}", "hipgraph": not args.no_graph},
                "loss": {"photo": loss_vals[0], "corr": loss_vals[1], "smooth": loss_vals[2], "total": loss_vals[3]},
-               "roofline": roof, "cpu_baseline": cpu, "dice": dice, "eval": ev_line}
+               "roofline": roof, "cpu_baseline": cpu, "dice": dice, "eval": ev_line, "volumes3d": vol_line}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
