@@ -253,10 +253,11 @@ int mireg_colsum(const void* g, long ld, long M, int C, float* out, int accumula
 
 /* ---- K20: Adam exactly as train.py:129 builds it (betas .9/.999, eps = lrMin = 1e-4) ---------- */
 typedef struct mireg_adam_job { float* p; const float* g; float* m; float* v; long n; } mireg_adam_job;
-/* *step_dev is incremented on device first (graph-replayable); grad_scale multiplies every gradient
- * (1/world_size after a sum all-reduce). */
-int mireg_adam_step(const mireg_adam_job* jobs_dev, int njobs, int* step_dev, float lr, float beta1, float beta2,
-                    float eps, float grad_scale, hipStream_t stream);
+/* tick != 0: *step_dev is incremented on device first (graph-replayable; exactly one launch per optimizer step
+ * ticks, the others of the same step pass 0); grad_scale multiplies every gradient (1/world_size after a sum
+ * all-reduce). */
+int mireg_adam_step(const mireg_adam_job* jobs_dev, int njobs, int* step_dev, int tick, float lr, float beta1,
+                    float beta2, float eps, float grad_scale, hipStream_t stream);
 
 
 /* ---- K7/K8: cost volume == external correlation_package.Correlation(pad=md, k=1, md, s1=1, s2) ------- */

@@ -894,10 +894,10 @@ int mireg_colsum(const void* g, long ld, long M, int C, float* out, int accumula
   MIREG_LAUNCH_RET();
 }
 
-int mireg_adam_step(const mireg_adam_job* jobs_dev, int njobs, int* step_dev, float lr, float beta1, float beta2, float eps,
-                    float grad_scale, hipStream_t stream) {
+int mireg_adam_step(const mireg_adam_job* jobs_dev, int njobs, int* step_dev, int tick, float lr, float beta1, float beta2,
+                    float eps, float grad_scale, hipStream_t stream) {
   MIREG_CHECK_ARG(jobs_dev && njobs > 0 && step_dev);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, step_dev);
+  if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, step_dev);
   hipLaunchKernelGGL(adam_kernel, dim3(njobs == 1 ? 4096 : (njobs <= 8 ? 256 : 8), njobs), dim3(256), 0, stream, jobs_dev, step_dev, lr, beta1, beta2, eps, grad_scale);
   MIREG_LAUNCH_RET();
 }

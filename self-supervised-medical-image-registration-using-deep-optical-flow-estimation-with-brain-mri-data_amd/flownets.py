@@ -423,6 +423,11 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
             return run
         return [decoder, encoder(self.PHASE_ENC[0]), encoder(self.PHASE_ENC[1])]
 
+    def phase_layers(self):
+        """(layer names, BatchNorm names) of every backward phase, in phase order."""
+        bn = lambda names: tuple(names) if self.bn else ()
+        return [(tuple(self.DEC_LAYERS), ()), (self.PHASE_ENC[0], bn(self.PHASE_ENC[0])), (self.PHASE_ENC[1], bn(self.PHASE_ENC[1]))]
+
     def phase_ranges(self) -> List[Tuple[int, int]]:
         bn = lambda names: names if self.bn else ()
         return [self.flat_range(self.DEC_LAYERS), self.flat_range(self.PHASE_ENC[0], bn(self.PHASE_ENC[0])),

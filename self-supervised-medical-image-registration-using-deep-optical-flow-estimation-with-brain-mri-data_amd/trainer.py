@@ -146,7 +146,7 @@ class RegistrationTrainer:
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-4,
                  lamb_da: float = 0.5, gamma: float = 100.0, zeta: float = 100.0, use_graph: bool = True,
                  process_group=None, sync_loss_stats: bool = False, overlap: bool = True, packed_optimizer: bool = True,
-                 autotune: bool = True, tune_cache: Optional[str] = None):
+                 autotune: bool = True, tune_cache: Optional[str] = None, overlap_optimizer: bool = True):
         self.model = model
         self.predictor = model.predictor
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -162,6 +162,10 @@ class RegistrationTrainer:
         self._seg_ranges = [None]
         self.packed = packed_optimizer
         self.autotune = autotune
+        self.overlap_optimizer = overlap_optimizer   # single GPU: Adam of a finished backward phase runs under the next phase
+        self._tuning = False
+        self._opt_stream = None
+        self._phase_tabs = None
         self.tune_cache = tune_cache        # JSON file of measured launch shapes: loaded if present, written after tuning
         self._packs_fresh = False
         self.flat_p = flatten_parameters(model)
@@ -200,6 +204,7 @@ class RegistrationTrainer:
                 o += p.numel()
             self._adam_tab, self._adam_n = upload_table(jobs, dev), len(jobs)
             self._wopt_tab = None
+            self._phase_tabs = None
         else:
             if self.flat_g is None:
                 self.flat_g = torch.zeros_like(self.flat_p)
@@ -231,12 +236,12 @@ class RegistrationTrainer:
         bufs = [b for b in self.model.buffers()]
         saved = [b.detach().clone() for b in bufs]
         ws, side = self.eng.ws, type(self.eng).use_side_stream
-        ws.tuning, self.eng.use_side_stream = True, False
+        ws.tuning, self.eng.use_side_stream, self._tuning = True, False, True
         try:
             self._fwd_bwd()
             torch.cuda.synchronize()
         finally:
-            ws.tuning, self.eng.use_side_stream = False, side
+            ws.tuning, self.eng.use_side_stream, self._tuning = False, side, False
             for b, v in zip(bufs, saved):
                 b.copy_(v)
             self.eng._reduce_table, self.eng._unpack_table = {}, None     # wgrad slabs may have been re-sized
@@ -252,8 +257,76 @@ class RegistrationTrainer:
         self.loss.finalize(Bg)
         return self.loss.backward(flows, Bg)
 
+    @property
+    def _phase_opt(self) -> bool:
+        return (self.packed and self.world == 1 and self.overlap_optimizer and not self._tuning
+                and hasattr(self.eng, "backward_phases") and hasattr(self.eng, "phase_layers"))
+
     def _fwd_bwd(self) -> None:
-        self.eng.backward(self._forward_and_loss())
+        if not self._phase_opt:
+            self.eng.backward(self._forward_and_loss())
+            return
+        # single GPU: as soon as a backward phase has reduced its gradients, its Adam + FWD re-pack (HBM-bound) runs on a
+        # third stream underneath the next phase's contractions; a parallel hipGraph branch under capture
+        phases = self.eng.backward_phases(self._forward_and_loss())
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.flat_p.device)
+        main = torch.cuda.current_stream()
+        for k, phase in enumerate(phases):
+            phase()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._opt_stream.wait_event(ev)
+            with torch.cuda.stream(self._opt_stream):
+                self._optim_phase(k)
+        main.wait_stream(self._opt_stream)
+
+    def _build_phase_tab(self, k: int):
+        """Tables of phase k, built when the phase has run once (its wgrad slabs exist then)."""
+        base, dev = self.flat_p.data_ptr(), self.flat_p.device
+        off = self.eng.flat_off
+        phases = self.eng.phase_layers()
+        assert {n for names, _ in phases for n in names} == set(self.eng.layers), "every layer must belong to one backward phase"
+        for names, bn_names in phases[k:k + 1]:
+            small, jobs, units = [], [], 0
+            ps = []
+            for n in names:
+                l = self.eng.layers[n]
+                if l.bias is not None:
+                    ps.append(l.bias)
+                if l.wgrad_slab is None:
+                    continue
+                o = l.weight.data_ptr() - base
+                j = l.wopt_job(self.flat_m.data_ptr() + o, self.flat_v.data_ptr() + o)
+                j.unit0 = units
+                units += l.Co * ((l.Cip + 63) // 64)
+                jobs.append(j)
+            for n in bn_names:
+                ps += [self.eng.bns[n].bn.weight, self.eng.bns[n].bn.bias]
+            for p in ps:
+                o = p.data_ptr() - base
+                small.append(AdamJob(p.data_ptr(), self.flat_g.data_ptr() + 4 * off[id(p)], self.flat_m.data_ptr() + o,
+                                     self.flat_v.data_ptr() + o, p.numel()))
+            return (upload_table(small, dev) if small else None, len(small),
+                    upload_table(jobs, dev) if jobs else None, len(jobs), units, max([j.taps for j in jobs] or [1]),
+                    sum(self.eng.layers[n].weight.numel() for n in names))
+
+    def _optim_phase(self, k: int) -> None:
+        if self._phase_tabs is None:
+            self._phase_tabs = {}
+        if k not in self._phase_tabs:
+            self._phase_tabs[k] = self._build_phase_tab(k)
+        st = _stream()
+        small, ns, tab, n, units, max_taps, nparam = self._phase_tabs[k]
+        tick = 1 if k == 0 else 0
+        if tab is not None:
+            PROFILER.call("adam_pack", 30.0 * nparam, f"optimizer:phase{k}", "mireg_adam_pack", tab.data_ptr(), n, units, max_taps,
+                          self.step_dev.data_ptr(), tick, self.lr, self.betas[0], self.betas[1], self.eps, 1.0, self.eng.ws.code, st,
+                          unit="B")
+            tick = 0
+        if small is not None:
+            _lib.call("mireg_adam_step", small.data_ptr(), ns, self.step_dev.data_ptr(), tick, self.lr, self.betas[0], self.betas[1],
+                      self.eps, 1.0, st)
 
     def _segments(self):
         """[(callable, flat-gradient range or None)]: the step cut where gradient buckets complete (DP overlap)."""
@@ -272,7 +345,11 @@ class RegistrationTrainer:
 
     def _optim(self) -> None:
         st = _stream()
-        _lib.call("mireg_adam_step", self._adam_tab.data_ptr(), self._adam_n, self.step_dev.data_ptr(), self.lr, self.betas[0],
+        if self._phase_opt:                                 # Adam already ran phase by phase inside _fwd_bwd
+            self.eng.pack_weights(dgrad_only=True)
+            self._packs_fresh = True
+            return
+        _lib.call("mireg_adam_step", self._adam_tab.data_ptr(), self._adam_n, self.step_dev.data_ptr(), 1, self.lr, self.betas[0],
                   self.betas[1], self.eps, 1.0 / self.world, st)
         if not self.packed:
             return

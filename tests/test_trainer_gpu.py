@@ -151,7 +151,7 @@ def test_dp2_bucketed_overlap_on_one_gpu():
     model = mireg.opticalFlowReg("flownets", precision="fp32")
     nets.analytic_weights_(model)
     model = model.to(DEV)
-    tr = mireg.RegistrationTrainer(model, use_graph=False, autotune=False)
+    tr = mireg.RegistrationTrainer(model, use_graph=False, autotune=False, overlap_optimizer=False)
     # emulate DP: per step, grads of both halves summed, Adam scale 1/2  (BN stats per half, like per rank)
     tr._setup(x[:2].to(DEV))
     for _ in range(4):
