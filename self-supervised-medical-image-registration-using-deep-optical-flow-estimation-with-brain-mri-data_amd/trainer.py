@@ -262,6 +262,12 @@ class RegistrationTrainer:
         return (self.packed and self.world == 1 and self.overlap_optimizer and not self._tuning
                 and hasattr(self.eng, "backward_phases") and hasattr(self.eng, "phase_layers"))
 
+    @property
+    def _phase_opt_dp(self) -> bool:
+        """Data parallel: Adam of bucket k runs (on the optimizer stream) as soon as its all-reduce has landed."""
+        return (self.packed and self.world > 1 and self.overlap and self.overlap_optimizer and not self._tuning
+                and hasattr(self.eng, "backward_phases") and hasattr(self.eng, "phase_layers"))
+
     def _fwd_bwd(self) -> None:
         if not self._phase_opt:
             self.eng.backward(self._forward_and_loss())
@@ -311,7 +317,7 @@ class RegistrationTrainer:
                     upload_table(jobs, dev) if jobs else None, len(jobs), units, max([j.taps for j in jobs] or [1]),
                     sum(self.eng.layers[n].weight.numel() for n in names))
 
-    def _optim_phase(self, k: int) -> None:
+    def _optim_phase(self, k: int, scale: float = 1.0) -> None:
         if self._phase_tabs is None:
             self._phase_tabs = {}
         if k not in self._phase_tabs:
@@ -321,12 +327,12 @@ class RegistrationTrainer:
         tick = 1 if k == 0 else 0
         if tab is not None:
             PROFILER.call("adam_pack", 30.0 * nparam, f"optimizer:phase{k}", "mireg_adam_pack", tab.data_ptr(), n, units, max_taps,
-                          self.step_dev.data_ptr(), tick, self.lr, self.betas[0], self.betas[1], self.eps, 1.0, self.eng.ws.code, st,
+                          self.step_dev.data_ptr(), tick, self.lr, self.betas[0], self.betas[1], self.eps, scale, self.eng.ws.code, st,
                           unit="B")
             tick = 0
         if small is not None:
             _lib.call("mireg_adam_step", small.data_ptr(), ns, self.step_dev.data_ptr(), tick, self.lr, self.betas[0], self.betas[1],
-                      self.eps, 1.0, st)
+                      self.eps, scale, st)
 
     def _segments(self):
         """[(callable, flat-gradient range or None)]: the step cut where gradient buckets complete (DP overlap)."""
@@ -345,7 +351,7 @@ class RegistrationTrainer:
 
     def _optim(self) -> None:
         st = _stream()
-        if self._phase_opt:                                 # Adam already ran phase by phase inside _fwd_bwd
+        if self._phase_opt or self._phase_opt_dp:           # Adam already ran phase by phase (inside _fwd_bwd / _run)
             self.eng.pack_weights(dgrad_only=True)
             self._packs_fresh = True
             return
@@ -376,11 +382,25 @@ class RegistrationTrainer:
         """runners[i]() executes segment i (eagerly or as a hipGraph replay); finished buckets are all-reduced
         asynchronously (RCCL runs on its own stream) while the next segment computes."""
         works = []
-        for run, rng in zip(runners, self._seg_ranges):
+        dp_opt = self._phase_opt_dp and len(runners) == len(self.eng.phase_layers())
+        if dp_opt and self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.flat_p.device)
+
+        def optimise(k: int) -> None:                      # on the optimizer stream, behind bucket k's all-reduce
+            with torch.cuda.stream(self._opt_stream):
+                works[k].wait()
+                self._optim_phase(k, 1.0 / self.world)
+        for k, (run, rng) in enumerate(zip(runners, self._seg_ranges)):
             run()
             if self.world > 1:
                 buf = self.flat_g if rng is None else self.flat_g[rng[0]:rng[1]]
                 works.append(torch.distributed.all_reduce(buf, group=self.pg, async_op=True))
+                if dp_opt and k > 0:
+                    optimise(k - 1)
+        if dp_opt:
+            optimise(len(works) - 1)
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            return
         for w in works:
             w.wait()
 
