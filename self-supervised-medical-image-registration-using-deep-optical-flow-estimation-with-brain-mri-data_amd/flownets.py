@@ -78,6 +78,20 @@ class PredictorEngineBase:
     # flat gradient the fused optimizer consumes (RegistrationTrainer), and the optimizer keeps the packs fresh.
     grad_mode = "torch"
     packs_fresh = False
+    # True: a backward phase ends WITHOUT joining the wgrad stream / reducing its slabs (the caller does both); kept
+    # for experiments -- measured slower than the default, see RegistrationTrainer._fwd_bwd
+    defer_grad_reduce = False
+
+    def pack_dgrad_subset(self, names: Sequence[str]) -> None:
+        """DGRAD packs of the named layers from their (fresh) FWD packs."""
+        key = ("dgrad", tuple(names))
+        if key not in self._reduce_table:
+            jobs = [j for n in names for j in self.layers[n].pack_jobs()]
+            _, dunits = assign_tiles(jobs, False)
+            self._reduce_table[key] = (upload_table(jobs, self.ws.device), len(jobs), dunits) if dunits else None
+        if self._reduce_table[key] is not None:
+            tab, n, dunits = self._reduce_table[key]
+            _lib.call("mireg_pack_weights", tab.data_ptr(), n, 0, dunits, self.ws.code, _stream())
 
     def pack_weights(self, force: bool = False, dgrad_only: bool = False) -> None:
         """torch-layout fp32 parameters -> GEMM packs (one table-driven launch)."""
@@ -409,8 +423,9 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
 
         def decoder():
             self.decoder_backward({2: g[1], 3: g[2], 4: g[3], 5: g[4], 6: g[5]}, g[0])
-            self.join_side()
-            self.unpack_grads(self.DEC_LAYERS)
+            if not self.defer_grad_reduce:
+                self.join_side()
+                self.unpack_grads(self.DEC_LAYERS)
 
         def encoder(names):
             def run():
@@ -418,8 +433,9 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
                     src, dst = self.enc_io[name]
                     dsrc, acc, ddst = self.enc_dio[name]
                     self.chain_backward(name, src, dst, dsrc, acc, ddst)
-                self.join_side()
-                self.unpack_grads(names)
+                if not self.defer_grad_reduce:
+                    self.join_side()
+                    self.unpack_grads(names)
             return run
         return [decoder, encoder(self.PHASE_ENC[0]), encoder(self.PHASE_ENC[1])]
 

@@ -274,17 +274,21 @@ class RegistrationTrainer:
             return
         # single GPU: as soon as a backward phase has reduced its gradients, its Adam + FWD re-pack (HBM-bound) runs on a
         # third stream underneath the next phase's contractions; a parallel hipGraph branch under capture
+        # (measured: also moving the slab reduce and the wgrad-stream join off the main stream is 3 % SLOWER -- three
+        # concurrent kernel streams thrash each other; so only the HBM-bound optimizer work leaves the main stream)
         phases = self.eng.backward_phases(self._forward_and_loss())
+        names = [n for n, _ in self.eng.phase_layers()]
         if self._opt_stream is None:
             self._opt_stream = torch.cuda.Stream(device=self.flat_p.device)
         main = torch.cuda.current_stream()
         for k, phase in enumerate(phases):
-            phase()
+            phase()                                         # ends with the wgrad-stream join and the slab reduce
             ev = torch.cuda.Event()
             ev.record(main)
             self._opt_stream.wait_event(ev)
             with torch.cuda.stream(self._opt_stream):
                 self._optim_phase(k)
+                self.eng.pack_dgrad_subset(names[k])
         main.wait_stream(self._opt_stream)
 
     def _build_phase_tab(self, k: int):
@@ -351,7 +355,10 @@ class RegistrationTrainer:
 
     def _optim(self) -> None:
         st = _stream()
-        if self._phase_opt or self._phase_opt_dp:           # Adam already ran phase by phase (inside _fwd_bwd / _run)
+        if self._phase_opt:                                 # Adam and both re-packs already ran phase by phase inside _fwd_bwd
+            self._packs_fresh = True
+            return
+        if self._phase_opt_dp:                              # Adam ran per bucket inside _run
             self.eng.pack_weights(dgrad_only=True)
             self._packs_fresh = True
             return
@@ -421,7 +428,8 @@ class RegistrationTrainer:
             if self._graphs is None:
                 self._capture()
             self._run([g.replay for g in self._graphs])
-            self._graph_opt.replay()
+            if self._graph_opt is not None:
+                self._graph_opt.replay()
         else:
             segs = self._segments()
             self._seg_ranges = [r for _, r in segs]
@@ -443,9 +451,13 @@ class RegistrationTrainer:
                 with torch.cuda.graph(gr, stream=s):
                     fn()
                 self._graphs.append(gr)
-            self._graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_opt, stream=s):
+            if self._phase_opt:                             # nothing left to launch after the backward graph
+                self._graph_opt = None
                 self._optim()
+            else:
+                self._graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_opt, stream=s):
+                    self._optim()
         torch.cuda.current_stream().wait_stream(s)
         self._graph_fb = self._graphs[0]
 
