@@ -157,6 +157,14 @@ def main():
         summ = PROFILER.summary()
         hbm = PROFILER.summary(bytes_=True)
         PROFILER.enabled = False
+        # same launches with nothing else in flight (no wgrad stream, no optimizer stream): the kernels' own rate
+        trainer.eng.use_side_stream, trainer.overlap_optimizer = False, False
+        PROFILER.enabled, PROFILER.records, PROFILER.byte_records = True, [], []
+        for _ in range(2):
+            trainer._fwd_bwd()
+        iso = PROFILER.summary()
+        PROFILER.enabled = False
+        trainer.eng.use_side_stream, trainer.overlap_optimizer = True, True
         dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
         tot_fl = sum(v["flops"] for v in summ.values())
         tot_ms = sum(v["ms"] for v in summ.values())
@@ -167,6 +175,10 @@ def main():
                 "avg_launch_us": round(dom[1]["ms"] * 1e3 / dom[1]["launches"], 2), "launches_per_step": dom[1]["launches"] // 3,
                 "all_contractions": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_step": round(tot_ms / 3, 3),
                                      "gflop_per_step": round(tot_fl / 3 / 1e9, 1)},
+                "isolated": {"note": "same launches, single stream (nothing overlapping)",
+                             "kernel_tflops": round(iso[dom[0]]["flops"] / (iso[dom[0]]["ms"] * 1e-3) / 1e12, 1),
+                             "kernel_frac": round(iso[dom[0]]["flops"] / (iso[dom[0]]["ms"] * 1e-3) / 1e12 / peak, 4),
+                             "all_contractions_tflops": round(sum(v["flops"] for v in iso.values()) / (sum(v["ms"] for v in iso.values()) * 1e-3) / 1e12, 1)},
                 "families": {k: {"launches_per_step": v["launches"] // 3, "ms_per_step": round(v["ms"] / 3, 3),
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in summ.items()},
                 # HBM-bound kernels of the step: algorithmic bytes / event-timed duration vs 8 TB/s

@@ -6,6 +6,8 @@ for r in rows:
 rows.sort(key=lambda r: r["s"])
 marks = [i for i, r in enumerate(rows) if (sys.argv[2] if len(sys.argv) > 2 else "adam_pack") in r["Kernel_Name"]]
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+per = int(sys.argv[5]) if len(sys.argv) > 5 else 1          # marker occurrences per step
+marks = marks[per - 1::per]
 a, b = marks[-1 - k], marks[-k]
 win = rows[a + 1:b + 1]
 t0, t1 = win[0]["s"], win[-1]["e"]
