@@ -58,14 +58,24 @@ class PredictorEngineBase:
     # forked onto a second HIP stream (captured as a parallel hipGraph branch) and joined before the unpack.
     use_side_stream = True
 
-    def wgrad_async(self, lay: ConvLayer, x: View, dy: View, slot: int = 0) -> None:
+    def mark(self):
+        """Event on the current stream: 'the operands of a later wgrad_async(..., after=ev) are ready here'."""
+        if not self.use_side_stream:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def wgrad_async(self, lay: ConvLayer, x: View, dy: View, slot: int = 0, after=None) -> None:
         if not self.use_side_stream:
             lay.run_wgrad(x, dy, slot)
             return
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.ws.device)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        ev = after
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
         self._side.wait_event(ev)
         with torch.cuda.stream(self._side):
             lay.run_wgrad(x, dy, slot)
@@ -329,9 +339,11 @@ class FlowNetDecoderMixin:
             lrelu_bwd(ddst, dst, SLOPE, self.ws)
             dy = ddst
             lay.run_bias_grad(dy, accumulate=slot > 0)
-        self.wgrad_async(lay, src, dy, slot)
+        # the backward-data GEMM is on the critical chain: enqueue it first, the backward-weights GEMM (same inputs) after it
+        ready = self.mark()
         if dsrc is not None:
             lay.run_dgrad_form(dy, dsrc, accumulate=acc)
+        self.wgrad_async(lay, src, dy, slot, after=ready)
 
 
 class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
