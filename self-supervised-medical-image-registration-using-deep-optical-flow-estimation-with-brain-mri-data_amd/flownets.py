@@ -299,9 +299,12 @@ class FlowNetDecoderMixin:
 
         load_loss_grad(2)
         pf = L["predict_flow2"]
-        self.wgrad_async(pf, c[2], self.dflowT[2])
+        # everywhere below: mark() where a layer's wgrad operands are final, enqueue the critical-chain kernels first and
+        # the side-stream wgrad (waiting only for that mark) after them -- hipGraph launches nodes in capture order
+        ready = self.mark()
         pf.run_bias_grad(self.dflowT[2])
         pf.run_dgrad_form(self.dflowT[2], dc[2])                              # dcat2 <- (beta 0)
+        self.wgrad_async(pf, c[2], self.dflowT[2], after=ready)
         for lvl in (2, 3, 4, 5):
             # dcat[lvl] holds every decoder-side contribution now; push it one level coarser
             cs, cd = self.skip_c[lvl], DECONV[lvl][1]
@@ -310,21 +313,23 @@ class FlowNetDecoderMixin:
             gup = dc[lvl].slice(cs + cd, 2)
             up = L[f"up{lvl + 1}"]
             load_loss_grad(lvl + 1)                                           # dflowT[lvl+1] <- loss grad
-            self.wgrad_async(up, gup, self.flowT[lvl + 1])
+            m_up = self.mark()
             up.run_bias_grad(gup)
             up.run_fwd_form(gup, self.dflowT[lvl + 1], bias=False, accumulate=True)
+            self.wgrad_async(up, gup, self.flowT[lvl + 1], after=m_up)
             # feature deconv (lvl+1 -> lvl) + LeakyReLU
             gde = dc[lvl].slice(cs, cd)
             lrelu_bwd(gde, c[lvl].slice(cs, cd), SLOPE, self.ws)
             de = L[f"deconv{lvl}"]
-            self.wgrad_async(de, gde, feat_prev)
+            m_de = self.mark()
             de.run_bias_grad(gde)
             # predict_flow{lvl+1} writes dfeat_prev first (beta 0), the deconv then accumulates into it
             pfn = L[f"predict_flow{lvl + 1}"]
-            self.wgrad_async(pfn, feat_prev, self.dflowT[lvl + 1])
             pfn.run_bias_grad(self.dflowT[lvl + 1])
             pfn.run_dgrad_form(self.dflowT[lvl + 1], dfeat_prev)
             de.run_fwd_form(gde, dfeat_prev, bias=False, accumulate=True)
+            self.wgrad_async(de, gde, feat_prev, after=m_de)
+            self.wgrad_async(pfn, feat_prev, self.dflowT[lvl + 1], after=m_de)
 
     def chain_backward(self, name: str, src: View, dst: View, dsrc: Optional[View], acc: bool, ddst: View,
                        bn_key: Optional[str] = None, raw_key: Optional[str] = None, slot: int = 0,

@@ -149,17 +149,19 @@ class PWCEngine(PredictorEngineBase):
         lay = self.layers[name]
         if act:
             lrelu_bwd(dout, out, SLOPE, self.ws)
+        ready = self.mark()
         lay.run_bias_grad(dout, accumulate=slot > 0)
-        self.wgrad_async(lay, src, dout, slot)
         if dsrc is not None:
             lay.run_dgrad_form(dout, dsrc, accumulate=True)
+        self.wgrad_async(lay, src, dout, slot, after=ready)          # critical-chain kernels first (graph node order)
 
     def _deconv_bwd(self, name: str, g_fine: View, x_coarse: View, dx_coarse: View) -> None:
         """ConvTranspose2d(k4,s2,p1) backward: g_fine = grad wrt its (2x larger) output."""
         lay = self.layers[name]
+        ready = self.mark()
         lay.run_bias_grad(g_fine)
-        self.wgrad_async(lay, g_fine, x_coarse)
         lay.run_fwd_form(g_fine, dx_coarse, bias=False, accumulate=True)
+        self.wgrad_async(lay, g_fine, x_coarse, after=ready)
 
     def backward(self, gflows) -> None:
         """gflows: gradients wrt (flow0 .. flow6) as (B,2,h,w) fp32 or None."""
