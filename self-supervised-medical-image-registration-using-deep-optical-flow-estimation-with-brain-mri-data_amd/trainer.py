@@ -281,14 +281,20 @@ class RegistrationTrainer:
         if self._opt_stream is None:
             self._opt_stream = torch.cuda.Stream(device=self.flat_p.device)
         main = torch.cuda.current_stream()
-        for k, phase in enumerate(phases):
-            phase()                                         # ends with the wgrad-stream join and the slab reduce
-            ev = torch.cuda.Event()
-            ev.record(main)
+        def optimise(k: int, ev) -> None:
             self._opt_stream.wait_event(ev)
             with torch.cuda.stream(self._opt_stream):
                 self._optim_phase(k)
                 self.eng.pack_dgrad_subset(names[k])
+        evs = []
+        for k, phase in enumerate(phases):
+            phase()                                         # ends with the wgrad-stream join and the slab reduce
+            ev = torch.cuda.Event()
+            ev.record(main)
+            evs.append(ev)
+            if k > 0:                                       # enqueued one phase late (it only waits for its own phase's event):
+                optimise(k - 1, evs[k - 1])                 # hipGraph launches nodes in capture order, the chain goes first
+        optimise(len(phases) - 1, evs[-1])
         main.wait_stream(self._opt_stream)
 
     def _build_phase_tab(self, k: int):
