@@ -115,37 +115,70 @@ class FlowNetCEngine(PredictorEngineBase, FlowNetDecoderMixin):
         self.draw = {n: new(B, v.H, v.W, v.C) for n, v in self.raw.items()}
         self.grads_ready = True
 
-    def backward(self, gflows) -> None:
-        """gflows: gradients wrt (flow2, flow3, flow4, flow5, flow6) as (B,2,h,w) fp32 or None."""
+    DEC_LAYERS = [f"deconv{l}" for l in DECONV] + [f"predict_flow{l}" for l in PREDICT] + [f"up{l}" for l in (6, 5, 4, 3)]
+    PHASE_ENC = (("conv6_1", "conv6", "conv5_1", "conv5", "conv4_1", "conv4"), ("conv3_1", "conv_redir", "conv3", "conv2", "conv1"))
+
+    def _bn_names(self, names) -> tuple:
+        if not self.bn:
+            return ()
+        return tuple(k for n in names for k in ((n + "@a", n + "@b") if n in ("conv1", "conv2", "conv3") else (n,)))
+
+    def phase_layers(self):
+        return [(tuple(self.DEC_LAYERS), ()), (self.PHASE_ENC[0], self._bn_names(self.PHASE_ENC[0])),
+                (self.PHASE_ENC[1], self._bn_names(self.PHASE_ENC[1]))]
+
+    def phase_ranges(self):
+        return [self.flat_range(self.DEC_LAYERS), self.flat_range(self.PHASE_ENC[0], self._bn_names(self.PHASE_ENC[0])),
+                self.flat_range(self.PHASE_ENC[1], self._bn_names(self.PHASE_ENC[1]))]
+
+    def backward_phases(self, gflows):
+        """decoder | conv6_1..conv4 | conv3_1, conv_redir, cost volume, siamese conv3..conv1: in parameter order the tail,
+        the middle and the head of the flat gradient buffer (same contract as FlowNetSEngine.backward_phases)."""
         self._ensure_grad_buffers()
         c, dc = self.cat, self.dcat
         g = list(gflows) + [None] * (5 - len(gflows))
-        self.decoder_backward({2: g[0], 3: g[1], 4: g[2], 5: g[3], 6: g[4]}, None)
         cb = self.chain_backward
-        cb("conv6_1", self.a6, self.a61, self.da6, False, self.da61)
-        cb("conv6", c[5].slice(0, 512), self.a6, dc[5].slice(0, 512), True, self.da6)
-        cb("conv5_1", self.a5, c[5].slice(0, 512), self.da5, False, dc[5].slice(0, 512))
-        cb("conv5", c[4].slice(0, 512), self.a5, dc[4].slice(0, 512), True, self.da5)
-        cb("conv4_1", self.a4, c[4].slice(0, 512), self.da4, False, dc[4].slice(0, 512))
-        cb("conv4", c[3].slice(0, 256), self.a4, dc[3].slice(0, 256), True, self.da4)
-        cb("conv3_1", self.in31, c[3].slice(0, 256), self.din31, False, dc[3].slice(0, 256))
-        # din31 = [d conv_redir out (32) | d corr out (441)]
-        cb("conv_redir", self.c3["a"], self.in31.slice(0, 32), self.dc3["a"], False, self.din31.slice(0, 32))
-        gcorr = self.din31.slice(32, 441)
-        lrelu_bwd(gcorr, self.in31.slice(32, 441), SLOPE, self.ws)
-        fa, fb = self.c3["a"], self.c3["b"]
-        _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, fa.ptr, fa.ld, fb.ptr, fb.ld, self.dc3["a"].ptr,
-                  self.dc3["a"].ld, self.dc3["b"].ptr, self.dc3["b"].ld, self.B, fa.H, fa.W, 256, 256, 20, 2, 1, 0,
-                  self.ws.code, _stream())
-        # siamese streams: same weights, wgrad slot per stream, shared BatchNorm parameter gradients accumulate
-        cb("conv3", c[2].slice(0, 128), fa, dc[2].slice(0, 128), True, self.dc3["a"], "conv3@a", "conv3@a", 0, False)
-        cb("conv2", self.c1["a"], c[2].slice(0, 128), self.dc1["a"], False, dc[2].slice(0, 128), "conv2@a", "conv2@a", 0, False)
-        cb("conv1", self.xa, self.c1["a"], None, False, self.dc1["a"], "conv1@a", "conv1@a", 0, False)
-        cb("conv3", self.c2b, fb, self.dc2b, False, self.dc3["b"], "conv3@b", "conv3@b", 1, True)
-        cb("conv2", self.c1["b"], self.c2b, self.dc1["b"], False, self.dc2b, "conv2@b", "conv2@b", 1, True)
-        cb("conv1", self.xb, self.c1["b"], None, False, self.dc1["b"], "conv1@b", "conv1@b", 1, True)
-        self.join_side()
-        self.unpack_grads()
+
+        def decoder():
+            self.decoder_backward({2: g[0], 3: g[1], 4: g[2], 5: g[3], 6: g[4]}, None)
+            self.join_side()
+            self.unpack_grads(self.DEC_LAYERS)
+
+        def deep():
+            cb("conv6_1", self.a6, self.a61, self.da6, False, self.da61)
+            cb("conv6", c[5].slice(0, 512), self.a6, dc[5].slice(0, 512), True, self.da6)
+            cb("conv5_1", self.a5, c[5].slice(0, 512), self.da5, False, dc[5].slice(0, 512))
+            cb("conv5", c[4].slice(0, 512), self.a5, dc[4].slice(0, 512), True, self.da5)
+            cb("conv4_1", self.a4, c[4].slice(0, 512), self.da4, False, dc[4].slice(0, 512))
+            cb("conv4", c[3].slice(0, 256), self.a4, dc[3].slice(0, 256), True, self.da4)
+            self.join_side()
+            self.unpack_grads(self.PHASE_ENC[0])
+
+        def shallow():
+            cb("conv3_1", self.in31, c[3].slice(0, 256), self.din31, False, dc[3].slice(0, 256))
+            # din31 = [d conv_redir out (32) | d corr out (441)]
+            cb("conv_redir", self.c3["a"], self.in31.slice(0, 32), self.dc3["a"], False, self.din31.slice(0, 32))
+            gcorr = self.din31.slice(32, 441)
+            lrelu_bwd(gcorr, self.in31.slice(32, 441), SLOPE, self.ws)
+            fa, fb = self.c3["a"], self.c3["b"]
+            _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, fa.ptr, fa.ld, fb.ptr, fb.ld, self.dc3["a"].ptr,
+                      self.dc3["a"].ld, self.dc3["b"].ptr, self.dc3["b"].ld, self.B, fa.H, fa.W, 256, 256, 20, 2, 1, 0,
+                      self.ws.code, _stream())
+            # siamese streams: same weights, wgrad slot per stream, shared BatchNorm parameter gradients accumulate
+            cb("conv3", c[2].slice(0, 128), fa, dc[2].slice(0, 128), True, self.dc3["a"], "conv3@a", "conv3@a", 0, False)
+            cb("conv2", self.c1["a"], c[2].slice(0, 128), self.dc1["a"], False, dc[2].slice(0, 128), "conv2@a", "conv2@a", 0, False)
+            cb("conv1", self.xa, self.c1["a"], None, False, self.dc1["a"], "conv1@a", "conv1@a", 0, False)
+            cb("conv3", self.c2b, fb, self.dc2b, False, self.dc3["b"], "conv3@b", "conv3@b", 1, True)
+            cb("conv2", self.c1["b"], self.c2b, self.dc1["b"], False, self.dc2b, "conv2@b", "conv2@b", 1, True)
+            cb("conv1", self.xb, self.c1["b"], None, False, self.dc1["b"], "conv1@b", "conv1@b", 1, True)
+            self.join_side()
+            self.unpack_grads(self.PHASE_ENC[1])
+        return [decoder, deep, shallow]
+
+    def backward(self, gflows) -> None:
+        """gflows: gradients wrt (flow2, flow3, flow4, flow5, flow6) as (B,2,h,w) fp32 or None."""
+        for phase in self.backward_phases(gflows):
+            phase()
 
 
 class _FlowNetCFn(torch.autograd.Function):

@@ -319,7 +319,11 @@ class RegistrationTrainer:
                 jobs.append(j)
             for n in bn_names:
                 ps += [self.eng.bns[n].bn.weight, self.eng.bns[n].bn.bias]
+            seen = set()
             for p in ps:
+                if id(p) in seen:                           # siamese streams share their BatchNorm parameters
+                    continue
+                seen.add(id(p))
                 o = p.data_ptr() - base
                 small.append(AdamJob(p.data_ptr(), self.flat_g.data_ptr() + 4 * off[id(p)], self.flat_m.data_ptr() + o,
                                      self.flat_v.data_ptr() + o, p.numel()))

@@ -106,7 +106,7 @@ def test_evaluate_dice_matches_oracle():
     assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == len(list(model.parameters()))
 
 
-def _dp_worker(rank, world, port, ret):
+def _dp_worker(rank, world, port, ret, name="flownets", size=64):
     """Two ranks share cuda:0 over gloo (RCCL refuses two ranks on one device): exercises the bucketed,
     phase-overlapped gradient exchange of the trainer, eager and under hipGraph replay."""
     import os
@@ -117,10 +117,10 @@ def _dp_worker(rank, world, port, ret):
     from mireg.synth import make_pairs
     torch.cuda.set_device(0)
     torch.manual_seed(1)
-    model = mireg.opticalFlowReg("flownets", precision="fp32")
+    model = mireg.opticalFlowReg(name, precision="fp32")
     nets.analytic_weights_(model)
     model = model.to(DEV)
-    x, _ = make_pairs(4, 64, seed=3)
+    x, _ = make_pairs(4, size, seed=3)
     tr = mireg.RegistrationTrainer(model, use_graph=True, autotune=False)
     assert tr.world == 2
     xs = x[rank * 2:(rank + 1) * 2].to(DEV)
@@ -139,16 +139,29 @@ def test_dp2_bucketed_overlap_on_one_gpu():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     import tempfile, os
     tmp = tempfile.mkdtemp(prefix="mireg_dp_")           # results travel as files: no manager process to lose
-    mp.spawn(_dp_worker, args=(2, port, tmp), nprocs=2, join=True)
+    _dp_compare("flownets", 64, port, tmp)
+
+
+def test_dp2_bucketed_overlap_flownetc_on_one_gpu():
+    """Same exchange for FlowNetC: three buckets (decoder | conv6_1..conv4 | conv3_1, conv_redir, siamese conv3..conv1)."""
+    import socket, tempfile
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    _dp_compare("flownetc", 128, port, tempfile.mkdtemp(prefix="mireg_dp_"))
+
+
+def _dp_compare(name, size, port, tmp):
+    import os
+    import torch.multiprocessing as mp
+    mp.spawn(_dp_worker, args=(2, port, tmp, name, size), nprocs=2, join=True)
     ret = {r: torch.load(os.path.join(tmp, f"rank{r}.pt")) for r in range(2)}
     assert torch.equal(ret[0], ret[1])                       # replicas stay identical
     # reference: same two half-batches, gradients averaged by hand, non-overlapped single process
     import mireg
     from mireg.synth import make_pairs
     torch.manual_seed(1)
-    x, _ = make_pairs(4, 64, seed=3)
+    x, _ = make_pairs(4, size, seed=3)
     flats = []
-    model = mireg.opticalFlowReg("flownets", precision="fp32")
+    model = mireg.opticalFlowReg(name, precision="fp32")
     nets.analytic_weights_(model)
     model = model.to(DEV)
     tr = mireg.RegistrationTrainer(model, use_graph=False, autotune=False, overlap_optimizer=False)
