@@ -245,6 +245,11 @@ int mireg_cast_to_f32(float* dst, long ld_d, const void* src, long ld_s, long M,
 /* x[:, c0:c0+nc] of an NCHW fp32 batch (train.py:44-46 hands NCHW) -> NHWC rows with pixel stride ld */
 int mireg_nchw_to_nhwc(const float* src, void* dst, int B, int Ctot, int c0, int nc, long HW, long ld, int dtype,
                        hipStream_t stream);
+/* clear a table of 16-byte aligned device buffers in one launch (the gradient accumulators PWCNet.py's autograd would
+ * allocate fresh per backward); unit0 = first 16 KiB block of the job, units = ceil(bytes / 16384) */
+typedef struct mireg_zero_job { void* p; long bytes; int unit0; int pad_; } mireg_zero_job;
+int mireg_zero_many(const mireg_zero_job* jobs_dev, int njobs, int total_units, hipStream_t stream);
+
 /* bias gradients: out[c] (+)= sum_m g[m][c], fixed summation order on the vector path (C % 8 == 0 for bf16 / % 4 fp32).
  * workspace: MIREG_COLSUM_MAX_SEGMENTS * C floats, needed once M > 8192 (row segments + finalize); may be NULL. */
 #define MIREG_COLSUM_MAX_SEGMENTS 64

@@ -577,6 +577,21 @@ colsum_finalize_kernel(const float* __restrict__ partial, int nseg, int C, float
   out[c] = accumulate ? out[c] + s : s;
 }
 
+// one launch that clears a table of buffers (gradient accumulators of a backward pass): block = 16 KiB of one buffer
+__global__ void __launch_bounds__(256) zero_many_kernel(const mireg_zero_job* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (jobs[mid].unit0 <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const mireg_zero_job j = jobs[lo];
+  const long base = (long)(blockIdx.x - j.unit0) * 16384;
+  unsigned char* p = reinterpret_cast<unsigned char*>(j.p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long o = base + ((long)i * 256 + threadIdx.x) * 16;
+    if (o + 16 <= j.bytes) *GPTR(uint4, p + o) = make_uint4(0u, 0u, 0u, 0u);
+    else for (long b = o; b < j.bytes && b < o + 16; ++b) p[b] = 0;
+  }
+}
+
 // fused multi-tensor Adam (torch.optim.Adam semantics, no weight decay / amsgrad); step lives on device so
 // the launch is hipGraph-replayable.  float4 streams: 28 B of traffic per parameter.
 __global__ void adam_tick_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
@@ -891,6 +906,12 @@ int mireg_colsum(const void* g, long ld, long M, int C, float* out, int accumula
   if (gy > 64) gy = 64;
   if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((colsum_kernel<__bf16>), dim3(C, (unsigned)gy), dim3(256), 0, stream, (const __bf16*)g, ld, M, C, out);
   else hipLaunchKernelGGL((colsum_kernel<float>), dim3(C, (unsigned)gy), dim3(256), 0, stream, (const float*)g, ld, M, C, out);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_zero_many(const mireg_zero_job* jobs_dev, int njobs, int total_units, hipStream_t stream) {
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && total_units > 0);
+  hipLaunchKernelGGL(zero_many_kernel, dim3(total_units), dim3(256), 0, stream, jobs_dev, njobs);
   MIREG_LAUNCH_RET();
 }
 

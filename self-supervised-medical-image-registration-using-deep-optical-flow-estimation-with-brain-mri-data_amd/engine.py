@@ -80,6 +80,20 @@ class TailJob(ctypes.Structure):
                 ("h", ctypes.c_int), ("w", ctypes.c_int), ("blk0", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
+class ZeroJob(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("bytes", ctypes.c_long), ("unit0", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+def zero_many_table(bufs: Sequence[torch.Tensor], device):
+    """(device table, n, units) for mireg_zero_many over whole tensors."""
+    jobs, u = [], 0
+    for b in bufs:
+        nb = b.numel() * b.element_size()
+        jobs.append(ZeroJob(b.data_ptr(), nb, u, 0))
+        u += (nb + 16383) // 16384
+    return upload_table(jobs, device), len(jobs), u
+
+
 class AdamJob(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
                 ("n", ctypes.c_long)]

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _lib
 from .correlation import Correlation, correlation_views, pwc_warp_views
-from .engine import F32, View, _stream, cast_from_f32, lrelu_bwd, nchw_to_view
+from .engine import F32, View, _stream, cast_from_f32, lrelu_bwd, nchw_to_view, zero_many_table
 from .flownets import PredictorEngineBase
 
 SLOPE = 0.1
@@ -168,8 +168,9 @@ class PWCEngine(PredictorEngineBase):
         self._ensure_grad_buffers()
         L, code, st, B = self.layers, self.ws.code, _stream(), self.B
         g = list(gflows) + [None] * (7 - len(gflows))
-        for buf in self._zero_list:
-            buf.zero_()
+        if getattr(self, "_zero_tab", None) is None:
+            self._zero_tab = zero_many_table(self._zero_list, self.ws.device)
+        _lib.call("mireg_zero_many", self._zero_tab[0].data_ptr(), self._zero_tab[1], self._zero_tab[2], st)
         for lvl in range(0, 7):                                   # loss gradients of the seven flows
             if g[lvl] is None:
                 self.dflowT[lvl].buf.zero_()
