@@ -65,6 +65,16 @@ correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__
   const T* a_row = f1 + (((long)b * H + y) * W + min(xa, W - 1)) * ld1;
   const bool a_ok = xa < W;
   for (int e = threadIdx.x; e < 32 * DD; e += 256) otile[e] = (T)0.f;   // out-of-image displacements stay zero
+  uint4 a_frag[16];                                          // f1 fragments of channels 0..255 (bf16 path)
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kk = 16 * i + 8 * h;
+      const bool ok = a_ok && kk < C;
+      const uint4 v = *GPTR(const uint4, a_row + (ok ? kk : 0));
+      a_frag[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+  }
   __syncthreads();
   for (int dyi = wid; dyi < D; dyi += 4) {
     const int yy = y + (dyi - R) * s2;
@@ -78,13 +88,32 @@ correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       if constexpr (sizeof(T) == 2) {
-#pragma unroll 4
-        for (int k = 0; k < C; k += 16) {                    // C % 8 == 0; a trailing half step is zero-filled
-          const int kk = k + 8 * h;
-          uint4 av = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
-          if (a_ok && kk < C) av = *GPTR(const uint4, a_row + kk);
-          if (b_ok && kk < C) bv = *GPTR(const uint4, b_row + kk);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+        // 256 channels at a time: all 16 f2 fragments of the row are requested before the first MFMA (one round of
+        // memory latency per displacement row instead of one per K-step); the f1 fragments (same for every dy and
+        // f2 tile) live in registers across the whole block
+        for (int kb = 0; kb < C; kb += 256) {
+          uint4 bv[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int kk = kb + 16 * i + 8 * h;
+            const bool ok = b_ok && kk < C;
+            const uint4 v = *GPTR(const uint4, b_row + (ok ? kk : 0));
+            bv[i] = ok ? v : make_uint4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (kb + 16 * i < C) {                             // block-uniform
+              uint4 av;
+              if (kb == 0) av = a_frag[i];
+              else {
+                const int kk = kb + 16 * i + 8 * h;
+                const bool ok = a_ok && kk < C;
+                const uint4 v = *GPTR(const uint4, a_row + (ok ? kk : 0));
+                av = ok ? v : make_uint4(0, 0, 0, 0);
+              }
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv[i]), acc, 0, 0, 0);
+            }
+          }
         }
       } else {
 #pragma unroll 2
