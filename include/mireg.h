@@ -77,11 +77,12 @@ int mireg_ofe_bwd_coef(const double* sums, const long* npix, int n, int B, doubl
 
 /* ---- fused multi-scale tail of the training step (train.py:50-52 + loss.py:66-84 over all flow scales) ----
  * one launch per phase for ALL scales: job i = scale i with its own buffers; blk0 = first virtual block,
- * blocks_i = ceil(B*h*w / 256), total_blocks = sum.  x = the (B,2,H,W) fp32 batch [fixed, moving].
+ * blocks_i = ceil(B*h*w / MIREG_TAIL_PIXELS_PER_BLOCK), total_blocks = sum.  x = the (B,2,H,W) fp32 batch [fixed, moving].
  *   mireg_tail_resize: moving_r = bilinear(moving, align_corners=True), fixed_r = bilinear(fixed, False)
  *   mireg_tail_fwd   : warped = stn(flow, moving_r); sums[slot][0..5] += moments(warped, fixed_r), [6] += smoothness
  *   mireg_tail_bwd   : gflow = d total / d flow from coef (mireg_ofe_bwd_coef row of the scale)
  * same per-element arithmetic as the per-scale entry points above. */
+#define MIREG_TAIL_PIXELS_PER_BLOCK 1024
 typedef struct mireg_tail_job {
   const float* flow; long fsb, fsc, fsp;
   float* moving_r; float* fixed_r; float* warped;

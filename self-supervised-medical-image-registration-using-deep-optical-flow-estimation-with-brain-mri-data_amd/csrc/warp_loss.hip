@@ -478,7 +478,9 @@ __device__ __forceinline__ int tail_find(const mireg_tail_job* __restrict__ jobs
 __global__ void __launch_bounds__(kThreads)
 tail_resize_kernel(const mireg_tail_job* __restrict__ jobs, int n, const float* __restrict__ x, int B, int H, int W) {
   const mireg_tail_job j = jobs[tail_find(jobs, n, blockIdx.x)];
-  const long npix = (long)j.h * j.w, i = (long)(blockIdx.x - j.blk0) * kThreads + threadIdx.x;
+  const long npix = (long)j.h * j.w;
+  for (int chunk = 0; chunk < MIREG_TAIL_PIXELS_PER_BLOCK / kThreads; ++chunk) {
+  const long i = ((long)(blockIdx.x - j.blk0) * (MIREG_TAIL_PIXELS_PER_BLOCK / kThreads) + chunk) * kThreads + threadIdx.x;
   if (i >= (long)B * npix) return;
   const int b = (int)(i / npix);
   const long pix = i - (long)b * npix;
@@ -498,6 +500,7 @@ tail_resize_kernel(const mireg_tail_job* __restrict__ jobs, int n, const float* 
     const float top = v00 * (1.f - lx) + v01 * lx, bot = v10 * (1.f - lx) + v11 * lx;
     (align ? j.moving_r : j.fixed_r)[i] = top * (1.f - ly) + bot * ly;
   }
+  }
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -505,9 +508,11 @@ tail_fwd_kernel(const mireg_tail_job* __restrict__ jobs, int n, int B) {
   __shared__ float red[7 * (kThreads / 64)];
   const mireg_tail_job j = jobs[tail_find(jobs, n, blockIdx.x)];
   const int h = j.h, w = j.w;
-  const long npix = (long)h * w, i = (long)(blockIdx.x - j.blk0) * kThreads + threadIdx.x;
+  const long npix = (long)h * w;
   float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (i < (long)B * npix) {
+  for (int chunk = 0; chunk < MIREG_TAIL_PIXELS_PER_BLOCK / kThreads; ++chunk) {     // fewer blocks = fewer f64 atomics per moment
+    const long i = ((long)(blockIdx.x - j.blk0) * (MIREG_TAIL_PIXELS_PER_BLOCK / kThreads) + chunk) * kThreads + threadIdx.x;
+    if (i >= (long)B * npix) continue;
     const int b = (int)(i / npix);
     const long pix = i - (long)b * npix;
     const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
@@ -524,7 +529,7 @@ tail_fwd_kernel(const mireg_tail_job* __restrict__ jobs, int n, int B) {
     const float o = nw * (wx0 * wy0) + ne * (wx1 * wy0) + sw * (wx0 * wy1) + se * (wx1 * wy1);
     j.warped[i] = o;
     const float fv = j.fixed_r[i];
-    acc[0] = o; acc[1] = fv; acc[2] = o * fv; acc[3] = o * o; acc[4] = fv * fv; acc[5] = charb(fv - o);
+    acc[0] += o; acc[1] += fv; acc[2] += o * fv; acc[3] += o * o; acc[4] += fv * fv; acc[5] += charb(fv - o);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const float val = f[c * j.fsc];
@@ -545,9 +550,11 @@ __global__ void __launch_bounds__(kThreads)
 tail_bwd_kernel(const mireg_tail_job* __restrict__ jobs, int n, int B) {
   const mireg_tail_job j = jobs[tail_find(jobs, n, blockIdx.x)];
   const int h = j.h, w = j.w;
-  const long npix = (long)h * w, i = (long)(blockIdx.x - j.blk0) * kThreads + threadIdx.x;
-  if (i >= (long)B * npix) return;
+  const long npix = (long)h * w;
   const float cp = j.coef[0], k1 = j.coef[1], k2 = j.coef[2], mx = j.coef[3], my = j.coef[4], cs = j.coef[5];
+  for (int chunk = 0; chunk < MIREG_TAIL_PIXELS_PER_BLOCK / kThreads; ++chunk) {
+  const long i = ((long)(blockIdx.x - j.blk0) * (MIREG_TAIL_PIXELS_PER_BLOCK / kThreads) + chunk) * kThreads + threadIdx.x;
+  if (i >= (long)B * npix) return;
   const int b = (int)(i / npix);
   const long pix = i - (long)b * npix;
   const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
@@ -580,6 +587,7 @@ tail_bwd_kernel(const mireg_tail_job* __restrict__ jobs, int n, int B) {
     if (x > 0) acc -= charb_grad(f[c * j.fsc - j.fsp] - val);
     acc *= cs;
     g[c * j.gsc] = g2[c] * 1.f + acc;
+  }
   }
 }
 

@@ -72,7 +72,7 @@ class FusedRegLoss:
                 j.gflow, j.gsb, j.gsc, j.gsp = g.data_ptr(), 2 * h * w, h * w, 1
                 j.sums, j.coef = self.sums[i].data_ptr(), self.coef[i].data_ptr()
                 j.h, j.w, j.blk0 = h, w, blk
-                blk += (self.B * h * w + 255) // 256
+                blk += (self.B * h * w + 1023) // 1024          # MIREG_TAIL_PIXELS_PER_BLOCK
                 jobs.append(j)
             self._tab, self._tab_blocks, self._tab_key = upload_table(jobs, self.dev), blk, key
         return self._tab, self._tab_blocks
