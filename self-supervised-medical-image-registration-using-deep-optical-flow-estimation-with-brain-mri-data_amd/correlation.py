@@ -40,17 +40,34 @@ class Correlation(nn.Module):
     def forward(self, in1: torch.Tensor, in2: torch.Tensor) -> torch.Tensor:
         if not in1.is_cuda:
             raise RuntimeError("mireg.Correlation runs on the MI355X only; there is no CPU fallback")
-        if in1.requires_grad or in2.requires_grad:
-            if torch.is_grad_enabled():
-                raise NotImplementedError("correlation backward is scheduled after the forward path (DESIGN.md section 9)")
+        return _CorrelationFn.apply(in1, in2, self.md, self.s2)
+
+
+class _CorrelationFn(torch.autograd.Function):
+    """NCHW fp32 front end of mireg_correlation_fwd / _bwd (exact-fp32 MFMA kernels)."""
+
+    @staticmethod
+    def forward(ctx, in1, in2, md, s2):
         B, C, H, W = in1.shape
         cp = rup(C, 4)
         a = torch.zeros(B, H, W, cp, device=in1.device, dtype=torch.float32)
         b = torch.zeros(B, H, W, cp, device=in1.device, dtype=torch.float32)
         a[..., :C] = in1.detach().permute(0, 2, 3, 1)
         b[..., :C] = in2.detach().permute(0, 2, 3, 1)
-        D = 2 * (self.md // self.s2) + 1
+        D = 2 * (md // s2) + 1
         out = torch.empty(B, H, W, D * D, device=in1.device, dtype=torch.float32)
         _lib.call("mireg_correlation_fwd", a.data_ptr(), cp, b.data_ptr(), cp, out.data_ptr(), D * D, B, H, W, cp, C,
-                  self.md, self.s2, 1.0, DT_F32, _stream())
+                  md, s2, 1.0, DT_F32, _stream())
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (B, C, H, W, cp, D, md, s2)
         return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        B, C, H, W, cp, D, md, s2 = ctx.cfg
+        gn = g.permute(0, 2, 3, 1).contiguous().float()                       # (B, H, W, D*D)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        _lib.call("mireg_correlation_bwd", gn.data_ptr(), D * D, a.data_ptr(), cp, b.data_ptr(), cp, da.data_ptr(), cp,
+                  db.data_ptr(), cp, B, H, W, cp, C, md, s2, 0, 0, DT_F32, _stream())
+        return da[..., :C].permute(0, 3, 1, 2), db[..., :C].permute(0, 3, 1, 2), None, None

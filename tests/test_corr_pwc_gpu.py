@@ -214,3 +214,19 @@ def test_pwcnet_training_gradients_match_oracle():
             worst = (k, rel)
         assert rel < 2e-2, (k, rel)
     print("worst relative L2 gradient error", worst)
+
+
+def test_correlation_module_backward_matches_oracle_autograd():
+    """mireg.Correlation is differentiable like the upstream correlation_package op it replaces."""
+    import mireg
+    for (md, s2, C, H, W, B) in ((20, 2, 48, 12, 20, 2), (4, 1, 30, 9, 11, 1)):
+        f1 = (nets.analytic_input((B, C, H, W), seed=1) - 0.5)
+        f2 = (nets.analytic_input((B, C, H, W), seed=2) - 0.5)
+        D = 2 * (md // s2) + 1
+        g = nets.analytic_input((B, D * D, H, W), seed=3) - 0.5
+        a, b = f1.clone().requires_grad_(), f2.clone().requires_grad_()
+        (oops.correlation(a, b, md, 1, md, 1, s2, 1) * g).sum().backward()
+        ad, bd = f1.clone().to(DEV).requires_grad_(), f2.clone().to(DEV).requires_grad_()
+        out = mireg.Correlation(md, 1, md, 1, s2, 1)(ad, bd)
+        (out * g.to(DEV)).sum().backward()
+        assert _rel(ad.grad, a.grad) < 3e-5 and _rel(bd.grad, b.grad) < 3e-5, (md, s2)
