@@ -6,13 +6,14 @@ Everything computes through libmireg_hip.so (hand-written gfx950 kernels); nothi
 back to ATen/MIOpen or to the CPU oracle.
 """
 from . import _lib  # noqa: F401
-from .ops import OFEloss, dice_average, dice_batch, resize_bilinear, seg_round, stn  # noqa: F401
+from .ops import (OFEloss, correlation_loss, dice_average, dice_batch, photometric_loss, resize_bilinear, seg_round,  # noqa: F401
+                  smoothness_loss, stn)
 from .flownets import FlowNetS  # noqa: F401
 from .flownetc import FlowNetC  # noqa: F401
 from .pwcnet import PWCDCNet  # noqa: F401
 from .correlation import Correlation  # noqa: F401
-from .affine3d import Affloss, affmodel  # noqa: F401
+from .affine3d import Affloss, affmodel, correlation_loss_3d, photometric_loss_3d  # noqa: F401
 from .models import generate_grid, grid_generator, opticalFlowReg  # noqa: F401
 from .trainer import RegistrationTrainer  # noqa: F401
 
-__all__ = ["affmodel", "Affloss", "FlowNetS", "FlowNetC", "PWCDCNet", "Correlation", "opticalFlowReg", "RegistrationTrainer", "generate_grid", "grid_generator", "OFEloss", "dice_average", "dice_batch", "resize_bilinear", "seg_round", "stn"]
+__all__ = ["affmodel", "Affloss", "FlowNetS", "FlowNetC", "PWCDCNet", "Correlation", "opticalFlowReg", "RegistrationTrainer", "generate_grid", "grid_generator", "OFEloss", "photometric_loss", "correlation_loss", "smoothness_loss", "photometric_loss_3d", "correlation_loss_3d", "dice_average", "dice_batch", "resize_bilinear", "seg_round", "stn"]

@@ -159,3 +159,13 @@ def Affloss(warped: torch.Tensor, fixed: torch.Tensor, lamb_da: float = 1.0, gam
     # OFE finalisation with one scale: weight 0.05 -> fold 1/0.05 into gamma / zeta
     _lib.call("mireg_ofe_finalize", sums.data_ptr(), npix.data_ptr(), 1, B, 0.0, gamma / 0.05, lamb_da / 0.05, out.data_ptr(), st)
     return out[0], out[1], out[0] + out[1]
+
+
+def photometric_loss_3d(fixed: torch.Tensor, warped: torch.Tensor):
+    """Drop-in for reference loss.photometric_loss_3d (loss.py:16-19) -- value only."""
+    return Affloss(warped, fixed, 1.0, 1.0)[0]
+
+
+def correlation_loss_3d(fixed: torch.Tensor, warped: torch.Tensor):
+    """Drop-in for reference loss.correlation_loss_3d (loss.py:38-50) -- value only."""
+    return Affloss(warped, fixed, 1.0, 1.0)[1]

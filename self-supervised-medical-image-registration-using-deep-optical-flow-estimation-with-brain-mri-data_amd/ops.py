@@ -177,6 +177,30 @@ def OFEloss(flow: Sequence[torch.Tensor], warped: Sequence[torch.Tensor], fixed:
     return _OFELossFn.apply(fixed, lamb_da, gamma, zeta, n, *flow, *warped)
 
 
+def _single_scale_terms(fixed: torch.Tensor, warped: torch.Tensor, flow: torch.Tensor):
+    """(photometric, 1 - ncc, smoothness) of ONE scale through the OFEloss kernels: weight 0.05 * (1/n = 1) * 20 = 1."""
+    return _OFELossFn.apply(fixed, 20.0, 20.0, 20.0, 1, flow, warped)[:3]
+
+
+def photometric_loss(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference loss.photometric_loss (loss.py:9-14); differentiable wrt `warped`."""
+    B, _, h, w = warped.shape
+    return _single_scale_terms(fixed, warped, torch.zeros(B, 2, h, w, device=warped.device, dtype=F32))[0]
+
+
+def correlation_loss(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference loss.correlation_loss (loss.py:52-64), incl. the degenerate-input guard and the 1/B factor."""
+    B, _, h, w = warped.shape
+    return _single_scale_terms(fixed, warped, torch.zeros(B, 2, h, w, device=warped.device, dtype=F32))[1]
+
+
+def smoothness_loss(flow: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference loss.smoothness_loss (loss.py:23-30); differentiable wrt `flow`."""
+    B, _, h, w = flow.shape
+    z = torch.zeros(B, 1, h, w, device=flow.device, dtype=F32)
+    return _single_scale_terms(z, z, flow)[2]
+
+
 def seg_round(x: torch.Tensor) -> torch.Tensor:
     """clip(rint(x), 0, 3) on device (reference does a CPU numpy round trip, models.py:286)."""
     _need_gpu(x)

@@ -306,6 +306,23 @@ class PWCDCNet(nn.Module):
             self._engines[key] = PWCEngine(self, B, H, W, x.device, dtype)
         return self._engines[key]
 
+    def warp(self, x: torch.Tensor, flo: torch.Tensor) -> torch.Tensor:
+        """Drop-in for PWCDCNet.warp (PWC/models/PWCNet.py:143-179): x (B,C,H,W), flo (B,2,H,W) -> warped x * mask,
+        on the HIP kernel (values only; inside forward() the same kernel runs on the engine's NHWC buffers with its
+        backward)."""
+        if not x.is_cuda:
+            raise RuntimeError("mireg.PWCDCNet.warp runs on the MI355X only; there is no CPU fallback")
+        from .correlation import pwc_warp_views
+        from .engine import Workspace
+        B, C, H, W = x.shape
+        ws = Workspace(x.device, torch.float32)
+        xv, ov = ws.new(B, H, W, C), ws.new(B, H, W, C)
+        xv.buf[..., :C] = x.detach().float().permute(0, 2, 3, 1)
+        fv = ws.new(B, H, W, 2, dtype=torch.float32, pad=2)
+        fv.buf[...] = flo.detach().float().permute(0, 2, 3, 1)
+        pwc_warp_views(xv, fv, 1.0, ov, ws.code)
+        return ov.nchw()[:, :C].contiguous()
+
     def forward(self, x):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return tuple(_PWCFn.apply(self, x.float(), *self.parameters()))

@@ -59,6 +59,9 @@ def test_pwc_warp_golden(golden):
         pwc_warp_views(xv, fv, 1.0, ov, ws.code)
         got = ov.nchw().cpu()[:, ::8]
         assert (got - torch.from_numpy(g[f"warp_{C}_{H}"])).abs().max().item() < 2e-5, (C, H)
+        import mireg
+        got2 = mireg.PWCDCNet(md=4, precision="fp32").warp(x.to(DEV), flo.to(DEV)).cpu()[:, ::8]      # the module method
+        assert (got2 - torch.from_numpy(g[f"warp_{C}_{H}"])).abs().max().item() < 2e-5, (C, H)
 
 
 def test_pwcnet_fp32_golden(golden):

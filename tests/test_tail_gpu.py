@@ -194,3 +194,23 @@ def test_dice_rejects_mismatched_shapes():
     b = torch.zeros(2, 1, 64, 64, device=DEV)
     with pytest.raises(RuntimeError, match="differ in size"):
         mireg.dice_batch(a, b)
+
+
+def test_individual_loss_terms_match_oracle(golden):
+    """loss.py's photometric_loss / correlation_loss / smoothness_loss as stand-alone drop-ins (values and gradients)."""
+    import mireg
+    g = torch.Generator().manual_seed(5)
+    fixed = torch.rand(3, 1, 32, 40, generator=g)
+    warped = torch.rand(3, 1, 16, 20, generator=g)
+    flow = torch.randn(3, 2, 16, 20, generator=g)
+    wd, wo = warped.clone().to(DEV).requires_grad_(), warped.clone().requires_grad_()
+    fd, fo = flow.clone().to(DEV).requires_grad_(), flow.clone().requires_grad_()
+    pairs = [(mireg.photometric_loss(fixed.to(DEV), wd), oops.photometric_loss(fixed, wo)),
+             (mireg.correlation_loss(fixed.to(DEV), wd), oops.correlation_loss(fixed, wo)),
+             (mireg.smoothness_loss(fd), oops.smoothness_loss(fo))]
+    for a, b in pairs:
+        assert abs(a.item() - b.item()) <= 1e-5 * max(1.0, abs(b.item())), (a.item(), b.item())
+    (pairs[0][0] + pairs[1][0] + pairs[2][0]).backward()
+    (pairs[0][1] + pairs[1][1] + pairs[2][1]).backward()
+    assert (wd.grad.cpu() - wo.grad).abs().max().item() <= 2e-5 * max(1.0, wo.grad.abs().max().item())
+    assert (fd.grad.cpu() - fo.grad).abs().max().item() <= 2e-5 * max(1.0, fo.grad.abs().max().item())
