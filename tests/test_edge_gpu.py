@@ -138,3 +138,41 @@ def test_trainer_survives_a_short_last_batch():
     assert all(v == v and abs(v) < 1e9 for v in la + lb + lc)
     assert (tr.flat_p - w0).abs().max().item() > 0
     assert int(tr.step_dev.item()) == 6
+
+
+def test_full_size_properties_batch24_256():
+    """BASELINE configs[1] shape (24 pairs of 256x256, bf16), where the CPU oracle is too slow for a direct comparison:
+    size-independent properties instead -- run-to-run bit determinism, batch-permutation equivariance in eval mode,
+    identity behaviour of the warp at zero flow, and two identically seeded trainers staying bit-identical."""
+    import mireg
+    from mireg.synth import make_pairs
+    torch.manual_seed(1)
+    m = mireg.opticalFlowReg("flownets", precision="bf16")
+    nets.analytic_weights_(m)
+    m = m.to(DEV).eval()
+    x, _ = make_pairs(24, 256, seed=6)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        f1, w1, _, _ = m(xd)
+        f1 = [t.clone() for t in f1]
+        f2, w2, _, _ = m(xd)
+        assert all(torch.equal(a, b) for a, b in zip(f1, f2))                      # deterministic kernels
+        perm = torch.randperm(24, generator=torch.Generator().manual_seed(2)).to(DEV)
+        f3, _, _, _ = m(xd[perm].contiguous())
+        for a, b in zip(f1, f3):                                                    # eval-mode BN: samples independent
+            assert (a[perm] - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
+        zero = torch.zeros(24, 2, 256, 256, device=DEV)
+        wz = m.stn(zero, xd[:, 1:2].contiguous())
+        # (x+0)(w-1)/w sampling of the reference: interior pixels move by < 1 px; mean intensity is preserved to 1 %
+        assert abs(wz.mean().item() - xd[:, 1:2].mean().item()) <= 1e-2 * xd[:, 1:2].mean().item()
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(1)
+        mm = mireg.opticalFlowReg("flownets", precision="bf16")
+        nets.analytic_weights_(mm)
+        tr = mireg.RegistrationTrainer(mm.to(DEV), use_graph=True, autotune=False)
+        for _ in range(4):
+            loss = tr.step(xd)
+        outs.append((loss.clone(), tr.flat_p.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) or (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-9 * outs[0][0].abs().max().item()
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-7          # f64 moment atomics are the only unordered sums
