@@ -573,7 +573,8 @@ colsum_finalize_kernel(const float* __restrict__ partial, int nseg, int C, float
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
-  for (int k = 0; k < nseg; ++k) s += partial[(long)k * C + c];
+#pragma unroll 8
+  for (int k = 0; k < nseg; ++k) s += ldf(partial + (long)k * C + c);      // independent loads, summed in order
   out[c] = accumulate ? out[c] + s : s;
 }
 
