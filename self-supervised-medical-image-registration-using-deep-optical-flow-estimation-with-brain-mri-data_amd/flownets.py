@@ -181,7 +181,7 @@ class PredictorEngineBase:
         self._unpack_table, self._reduce_table = None, {}
         self.grad_mode = "packed"
 
-    def flat_range(self, layer_names: Sequence[str], bn_names: Sequence[str] = ()) -> Tuple[int, int]:
+    def flat_range(self, layer_names: Sequence[str], bn_names: Sequence[str] = (), extra: Sequence[nn.Parameter] = ()) -> Tuple[int, int]:
         """[start, end) of the flat gradient buffer covered by these layers' parameters (must be contiguous)."""
         ps = []
         for n in layer_names:
@@ -191,6 +191,7 @@ class PredictorEngineBase:
                 ps.append(l.bias)
         for n in bn_names:
             ps += [self.bns[n].bn.weight, self.bns[n].bn.bias]
+        ps += list(extra)                                   # parameters no layer of the engine uses (they sit inside the range)
         size = self.flat_size
         lo = min(self.flat_off[id(p)] for p in ps)
         hi = max(self.flat_off[id(p)] + size[id(p)] for p in ps)

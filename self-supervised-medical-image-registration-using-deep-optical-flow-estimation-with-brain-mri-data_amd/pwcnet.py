@@ -59,6 +59,7 @@ class PWCEngine(PredictorEngineBase):
                 self.add_conv(f"upfeat{lvl}", getattr(m, f"upfeat{lvl}"), 2, 1)
         self.add_conv("deconv2", m.deconv2, 2, 1)
         self.add_conv("deconv1", m.deconv1, 2, 1)
+        self._unused_tail = list(m.deconv0.parameters())     # defined, unused upstream (PWCNet.py:126,274): inside the tail bucket
         for i, (_, d) in enumerate(DC, start=1):
             self.add_conv(f"dc_conv{i}", getattr(m, f"dc_conv{i}")[0], 1, d, d)
         self.add_conv("dc_conv7", m.dc_conv7, 1, 1)
@@ -163,8 +164,11 @@ class PWCEngine(PredictorEngineBase):
         lay.run_fwd_form(g_fine, dx_coarse, bias=False, accumulate=True)
         self.wgrad_async(lay, g_fine, x_coarse, after=ready)
 
-    def backward(self, gflows) -> None:
-        """gflows: gradients wrt (flow0 .. flow6) as (B,2,h,w) fp32 or None."""
+    phase_opt_single_gpu = False      # measured: the two extra wgrad-stream joins cost more (10.3 ms) than the overlap buys (10.1 ms)
+
+    def backward_phases(self, gflows, joined: bool = True):
+        """Backward cut where gradient buckets complete, in parameter order tail -> head:
+        [dc_conv*, deconv1/2, level-2 estimator] | [level 3..6 estimators, their flow / feature upsamplers] | [siamese pyramid]."""
         self._ensure_grad_buffers()
         L, code, st, B = self.layers, self.ws.code, _stream(), self.B
         g = list(gflows) + [None] * (7 - len(gflows))
@@ -176,18 +180,10 @@ class PWCEngine(PredictorEngineBase):
                 self.dflowT[lvl].buf.zero_()
             else:
                 nchw_to_view(g[lvl].contiguous(), 0, 2, self.dflowT[lvl])
-        # flow0 = deconv1(flow1), flow1 = deconv2(flow2)
-        self._deconv_bwd("deconv1", self.dflowT[0], self.flowT[1], self.dflowT[1])
-        self._deconv_bwd("deconv2", self.dflowT[1], self.flowT[2], self.dflowT[2])
-        # flow2 = predict_flow2(x2) + dc_conv7(dc_conv6(...dc_conv1(x2)))
-        dX2 = self.dx[2]
-        self._conv_bwd("dc_conv7", self.dc[5], self.dc7, self.dflowT[2], self.ddc[5], act=False)
-        for i in range(6, 0, -1):
-            src, dsrc = (self.dc[i - 2], self.ddc[i - 2]) if i > 1 else (self.x[2], dX2)
-            self._conv_bwd(f"dc_conv{i}", src, self.dc[i - 1], self.ddc[i - 1], dsrc)
         feat = lambda lvl, s: self.pyr[(lvl, s, 2)]
         dfeat = lambda lvl, s: self.dpyr[(lvl, s, 2)]
-        for lvl in (2, 3, 4, 5, 6):
+
+        def level(lvl):
             X, dX = self.x[lvl], self.dx[lvl]
             # predict_flow{lvl}: dflowT[lvl] now holds loss grad + everything pushed up from the finer level
             self._conv_bwd(f"predict_flow{lvl}", X, self.flowT[lvl], self.dflowT[lvl], dX, act=False)
@@ -203,7 +199,7 @@ class PWCEngine(PredictorEngineBase):
                 d1, d2 = dfeat(6, "a"), dfeat(6, "b")
                 _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, c1.ptr, c1.ld, c2.ptr, c2.ld, d1.ptr, d1.ld, d2.ptr,
                           d2.ld, B, c1.H, c1.W, cp, FEAT_C[6], self.md, 1, 1, 1, code, st)
-                continue
+                return
             wv, dw, d1 = self.warped[lvl], self.dwarped[lvl], dfeat(lvl, "a")
             _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, c1.ptr, c1.ld, wv.ptr, wv.ld, d1.ptr, d1.ld, dw.ptr, dw.ld,
                       B, c1.H, c1.W, cp, FEAT_C[lvl], self.md, 1, 1, 1, code, st)
@@ -223,19 +219,59 @@ class PWCEngine(PredictorEngineBase):
             _lib.call("mireg_copy_channels", dX.slice(o + 2, 2).ptr, dX.ld, gft.ptr, gft.ld, gft.rows, 2, 0, code, st)
             self._deconv_bwd(f"deconv{lvl + 1}", guf, self.flowT[lvl + 1], self.dflowT[lvl + 1])
             self._deconv_bwd(f"upfeat{lvl + 1}", gft, self.x[lvl + 1], self.dx[lvl + 1])
-        # siamese pyramid, coarse -> fine, one wgrad slot per stream
-        for slot, s_ in enumerate("ab"):
-            for lvl in range(6, 0, -1):
-                for i in (2, 1, 0):
-                    if i > 0:
-                        src, dsrc = self.pyr[(lvl, s_, i - 1)], self.dpyr[(lvl, s_, i - 1)]
-                    elif lvl > 1:
-                        src, dsrc = self.pyr[(lvl - 1, s_, 2)], self.dpyr[(lvl - 1, s_, 2)]
-                    else:
-                        src, dsrc = self.img[s_], None
-                    self._conv_bwd(PYR_NAMES[lvl][i], src, self.pyr[(lvl, s_, i)], self.dpyr[(lvl, s_, i)], dsrc, slot)
-        self.join_side()
-        self.unpack_grads()
+
+        def fine():
+            # flow0 = deconv1(flow1), flow1 = deconv2(flow2)
+            self._deconv_bwd("deconv1", self.dflowT[0], self.flowT[1], self.dflowT[1])
+            self._deconv_bwd("deconv2", self.dflowT[1], self.flowT[2], self.dflowT[2])
+            # flow2 = predict_flow2(x2) + dc_conv7(dc_conv6(...dc_conv1(x2)))
+            dX2 = self.dx[2]
+            self._conv_bwd("dc_conv7", self.dc[5], self.dc7, self.dflowT[2], self.ddc[5], act=False)
+            for i in range(6, 0, -1):
+                src, dsrc = (self.dc[i - 2], self.ddc[i - 2]) if i > 1 else (self.x[2], dX2)
+                self._conv_bwd(f"dc_conv{i}", src, self.dc[i - 1], self.ddc[i - 1], dsrc)
+            level(2)
+            if joined:
+                self.join_side()
+                self.unpack_grads(self.PHASES[0])
+
+        def coarse():
+            for lvl in (3, 4, 5, 6):
+                level(lvl)
+            if joined:
+                self.join_side()
+                self.unpack_grads(self.PHASES[1])
+
+        def pyramid():
+            # siamese pyramid, coarse -> fine, one wgrad slot per stream
+            for slot, s_ in enumerate("ab"):
+                for lvl in range(6, 0, -1):
+                    for i in (2, 1, 0):
+                        if i > 0:
+                            src, dsrc = self.pyr[(lvl, s_, i - 1)], self.dpyr[(lvl, s_, i - 1)]
+                        elif lvl > 1:
+                            src, dsrc = self.pyr[(lvl - 1, s_, 2)], self.dpyr[(lvl - 1, s_, 2)]
+                        else:
+                            src, dsrc = self.img[s_], None
+                        self._conv_bwd(PYR_NAMES[lvl][i], src, self.pyr[(lvl, s_, i)], self.dpyr[(lvl, s_, i)], dsrc, slot)
+            self.join_side()
+            self.unpack_grads(self.PHASES[2] if joined else None)
+        return [fine, coarse, pyramid]
+
+    PHASES = (tuple([f"dc_conv{i}" for i in range(1, 8)] + ["deconv1", "deconv2", "predict_flow2"] + [f"conv2_{j}" for j in range(5)]),
+              tuple(n for lvl in (3, 4, 5, 6) for n in [f"conv{lvl}_{j}" for j in range(5)] + [f"predict_flow{lvl}", f"deconv{lvl}", f"upfeat{lvl}"]),
+              tuple(n for lvl in range(1, 7) for n in PYR_NAMES[lvl]))
+
+    def phase_layers(self):
+        return [(self.PHASES[0], ()), (self.PHASES[1], ()), (self.PHASES[2], ())]
+
+    def phase_ranges(self):
+        return [self.flat_range(self.PHASES[0], (), self._unused_tail), self.flat_range(self.PHASES[1]), self.flat_range(self.PHASES[2])]
+
+    def backward(self, gflows) -> None:
+        """gflows: gradients wrt (flow0 .. flow6) as (B,2,h,w) fp32 or None."""
+        for phase in self.backward_phases(gflows, joined=False):   # one join + one reduce at the end
+            phase()
 
 
 class _PWCFn(torch.autograd.Function):

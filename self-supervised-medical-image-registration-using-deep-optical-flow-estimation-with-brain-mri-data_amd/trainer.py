@@ -260,7 +260,8 @@ class RegistrationTrainer:
     @property
     def _phase_opt(self) -> bool:
         return (self.packed and self.world == 1 and self.overlap_optimizer and not self._tuning
-                and hasattr(self.eng, "backward_phases") and hasattr(self.eng, "phase_layers"))
+                and hasattr(self.eng, "backward_phases") and hasattr(self.eng, "phase_layers")
+                and getattr(self.eng, "phase_opt_single_gpu", True))
 
     @property
     def _phase_opt_dp(self) -> bool:
