@@ -149,7 +149,16 @@ def test_dp2_bucketed_overlap_flownetc_on_one_gpu():
     _dp_compare("flownetc", 128, port, tempfile.mkdtemp(prefix="mireg_dp_"))
 
 
-def _dp_compare(name, size, port, tmp):
+def test_dp2_bucketed_overlap_pwc_on_one_gpu():
+    """PWC-DC-Net buckets (dc_conv + level 2 | levels 3..6 | pyramid).  Its warp backward scatters with fp32 atomics, so the
+    hand-averaged reference is compared through the update direction instead of element-wise: two identical single-process
+    runs already differ by cos = 0.97 after four Adam steps (noise-level gradients move by +-lr)."""
+    import socket, tempfile
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    _dp_compare("pwc", 128, port, tempfile.mkdtemp(prefix="mireg_dp_"), strict=False)
+
+
+def _dp_compare(name, size, port, tmp, strict=True):
     import os
     import torch.multiprocessing as mp
     mp.spawn(_dp_worker, args=(2, port, tmp, name, size), nprocs=2, join=True)
@@ -180,8 +189,16 @@ def _dp_compare(name, size, port, tmp):
         tr.world = 2
         tr._optim()
         tr.world = 1
-    diff = (tr.flat_p.cpu() - ret[0]).abs().max().item()
-    assert diff < 5e-6, diff
+    if strict:
+        diff = (tr.flat_p.cpu() - ret[0]).abs().max().item()
+        assert diff < 5e-6, diff
+    else:
+        torch.manual_seed(1)
+        m0 = mireg.opticalFlowReg(name, precision="fp32")
+        nets.analytic_weights_(m0)
+        p0 = torch.cat([q.detach().reshape(-1) for q in m0.parameters()])
+        da, db = (tr.flat_p.cpu() - p0).double(), (ret[0] - p0).double()
+        assert torch.nn.functional.cosine_similarity(da, db, dim=0).item() > 0.9
 
 
 def test_fused_multiscale_tail_equals_per_scale_kernels():
