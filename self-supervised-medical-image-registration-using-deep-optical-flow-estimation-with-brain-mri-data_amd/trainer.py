@@ -279,23 +279,22 @@ class RegistrationTrainer:
         # concurrent kernel streams thrash each other; so only the HBM-bound optimizer work leaves the main stream)
         phases = self.eng.backward_phases(self._forward_and_loss())
         names = [n for n, _ in self.eng.phase_layers()]
-        if self._opt_stream is None:
-            self._opt_stream = torch.cuda.Stream(device=self.flat_p.device)
+        # The optimizer work goes onto the engine's wgrad stream, right behind the phase's backward-weights GEMMs: the
+        # hipGraph executor maps parallel branches onto few hardware queues, and a third branch was observed to share the
+        # wgrad branch's queue and run only after ALL wgrads (i.e. at the very end of the step).  In-order on the wgrad
+        # stream it runs between the phases, underneath the next phase's main-chain kernels.
+        if getattr(self.eng, "_side", None) is None:
+            self.eng._side = torch.cuda.Stream(device=self.flat_p.device)
+        self._opt_stream = self.eng._side
         main = torch.cuda.current_stream()
-        def optimise(k: int, ev) -> None:
-            self._opt_stream.wait_event(ev)
-            with torch.cuda.stream(self._opt_stream):
-                self._optim_phase(k)
-                self.eng.pack_dgrad_subset(names[k])
-        evs = []
         for k, phase in enumerate(phases):
             phase()                                         # ends with the wgrad-stream join and the slab reduce
             ev = torch.cuda.Event()
             ev.record(main)
-            evs.append(ev)
-            if k > 0:                                       # enqueued one phase late (it only waits for its own phase's event):
-                optimise(k - 1, evs[k - 1])                 # hipGraph launches nodes in capture order, the chain goes first
-        optimise(len(phases) - 1, evs[-1])
+            self._opt_stream.wait_event(ev)
+            with torch.cuda.stream(self._opt_stream):
+                self._optim_phase(k)
+                self.eng.pack_dgrad_subset(names[k])
         main.wait_stream(self._opt_stream)
 
     def _build_phase_tab(self, k: int):
