@@ -127,7 +127,7 @@ def _dp_worker(rank, world, port, ret, name="flownets", size=64):
     for _ in range(4):
         tr.step(xs)
     torch.cuda.synchronize()
-    assert tr._graphs is not None and len(tr._graphs) == 3
+    assert tr._graphs is not None and len(tr._graphs) == len(tr.eng.phase_layers())
     torch.save(tr.flat_p.detach().cpu().clone(), os.path.join(ret, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
