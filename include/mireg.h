@@ -151,6 +151,9 @@ typedef struct mireg_conv_desc {
   /* output-column tile width of mireg_conv_gemm: 0 = by N (128 / 64 / 32); 64 or 128 forces it (the host picks the
    * width whose tile count fills the 256 CUs most evenly) */
   int tile_n;
+  /* mireg_conv_wgrad: LDS ring depth.  0 / 3 = three stages (48 KiB: three workgroups per CU, best stand-alone and when the
+   * wgrad stream is the long pole); 4 = four stages (64 KiB: two per CU, leaves more of each CU to the concurrent main chain) */
+  int stages;
 } mireg_conv_desc;
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream);
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);

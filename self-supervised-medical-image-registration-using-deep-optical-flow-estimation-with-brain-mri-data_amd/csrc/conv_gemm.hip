@@ -652,18 +652,19 @@ conv_wgrad_kernel(const mireg_conv_desc p) {
 // the transposing read ds_read_b64_tr_b16; its 4 rows-per-lane-group would hit the same banks on 256-B rows, so
 // 16-B chunks are XOR-swizzled with (pixel_row & 3) << 2 on the DMA source side and on the read side.
 // =====================================================================================================
-template <typename T>
+// STAGES = 3: with the two-pass epilogue the kernel needs 48 KiB of LDS, so three workgroups share a CU -- split-K launches
+// have 700-800 workgroups, which then are all resident at once (conv2's wgrad: 90 -> 69 us); 4 stages gain nothing elsewhere.
+template <typename T, int STAGES = 3>
 __global__ void __launch_bounds__(256)
 conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   constexpr int CPC = Cfg<T>::CPC, BK = Cfg<T>::BK, BM = 128, BN = 128;
   constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2;
-  constexpr int STAGES = 4;
   constexpr int ROWB = 128 * (int)sizeof(T);                     // bytes per pixel row of a tile
   constexpr int RPI = 1024 / ROWB;                               // pixel rows per DMA instruction (4 bf16 / 2 fp32)
   constexpr int CPR = ROWB / 16;                                 // 16-B chunks per row (16 / 32)
   constexpr int TILE_BYTES = BK * ROWB;                          // 8 KiB
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-  constexpr int EPI_BYTES = BM * BN * 4;
+  constexpr int EPI_BYTES = WTM * BN * 4;                        // the epilogue stages 64 rows per pass (two passes)
   constexpr int SMEM_BYTES = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
   constexpr int INSTR = TILE_BYTES / 1024;                       // 8 DMA instructions per tile, 2 per wave
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
@@ -829,7 +830,7 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   int it = 0;
   const int steady = nk - (STAGES - 1);
   for (; it < steady; ++it) {
-    wait_vmcnt<8>();                                               // 2 younger tiles x 4 DMAs stay in flight
+    wait_vmcnt<(STAGES - 2) * 4>();                                // STAGES-2 younger tiles x 4 DMAs stay in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #ifndef MIREG_ABL_NOISSUE
@@ -846,28 +847,33 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
     compute(it % STAGES);
   }
 
-  // ---- epilogue: accumulators -> LDS fp32 [128][128] -> float4 rows of the slab [z][Cout][Ktot] ----------
+  // ---- epilogue: accumulators -> LDS fp32 [64][128] per pass -> float4 rows of the slab [z][Cout][Ktot] ----------
   __syncthreads();
   float* ct = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        ct[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BN + wn * WTN + j * 32 + r] = acc[i][j][e];
-  __syncthreads();
   const int Cout = p.N;
   float* __restrict__ slab = p.slab + (long)blockIdx.z * Cout * Ktot;
   const bool vec = (Ktot % 4) == 0;
-  for (int c = tid; c < BM * (BN / 4); c += 256) {
-    const int ml = c / (BN / 4), nl = (c - ml * (BN / 4)) * 4;
-    const int m = m0 + ml, n = n0 + nl;
-    if (m >= Cout || n >= Ktot) continue;
-    const float4 v = *reinterpret_cast<const float4*>(ct + ml * BN + nl);
-    float* d = slab + (long)m * Ktot + n;
-    if (vec) stg_u4(d, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
-    else { const float vv[4] = {v.x, v.y, v.z, v.w}; for (int q = 0; q < 4 && n + q < Ktot; ++q) d[q] = vv[q]; }
+  for (int hp = 0; hp < 2; ++hp) {                                  // rows [64 hp, 64 hp + 64) of the tile
+    if (hp) __syncthreads();
+    if (wm == hp) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            ct[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BN + wn * WTN + j * 32 + r] = acc[i][j][e];
+    }
+    __syncthreads();
+    for (int c = tid; c < WTM * (BN / 4); c += 256) {
+      const int mr = c / (BN / 4), nl = (c - mr * (BN / 4)) * 4;
+      const int m = m0 + hp * WTM + mr, n = n0 + nl;
+      if (m >= Cout || n >= Ktot) continue;
+      const float4 v = *reinterpret_cast<const float4*>(ct + mr * BN + nl);
+      float* d = slab + (long)m * Ktot + n;
+      if (vec) stg_u4(d, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+      else { const float vv[4] = {v.x, v.y, v.z, v.w}; for (int q = 0; q < 4 && n + q < Ktot; ++q) d[q] = vv[q]; }
+    }
   }
 }
 
@@ -908,7 +914,9 @@ int launch_wgrad(const mireg_conv_desc& p, hipStream_t stream) {
   const int z = p.split_k > 1 ? p.split_k : 1;
   dim3 grid((unsigned)(((Cout + 127) / 128) * ((Ktot + 127) / 128)), 1, z);
   if (p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < (1L << 31) && p.w_bytes < (1L << 31))
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<T>), grid, dim3(256), 0, stream, p);
+    // 3 stages = 48 KiB LDS, three workgroups per CU; 4 stages = 64 KiB, two per CU (leaves more of the CU to a concurrent stream)
+    if (p.stages == 4) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 4>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 3>), grid, dim3(256), 0, stream, p);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, stream, p);
   return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;

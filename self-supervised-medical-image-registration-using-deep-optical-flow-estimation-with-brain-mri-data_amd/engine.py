@@ -50,7 +50,7 @@ class ConvDesc(ctypes.Structure):
                 ("n_cls", ctypes.c_int), ("cls", ConvCls * 4), ("slab_cls_stride", ctypes.c_long),
                 ("x_D", ctypes.c_int), ("taps_z", ctypes.c_int), ("mul_z", ctypes.c_int), ("off_z", ctypes.c_int),
                 ("step_z", ctypes.c_int), ("g_D", ctypes.c_int), ("y_D", ctypes.c_int), ("y_mul_z", ctypes.c_int),
-                ("y_off_z", ctypes.c_int), ("tile_n", ctypes.c_int)]
+                ("y_off_z", ctypes.c_int), ("tile_n", ctypes.c_int), ("stages", ctypes.c_int)]
 
 
 class PackClass(ctypes.Structure):
@@ -182,6 +182,7 @@ class Workspace:
         self.scratch_elems = 0
         # launch-shape autotuning (tile width x split-K per contraction site): `tuning` is on during the trainer's
         # discarded tuning pass, `tuned` maps a launch site to its measured-best (tile_n, split_k)
+        self.wgrad_stages = 3                              # mireg_conv_desc.stages of the backward-weights GEMM (3 or 4)
         self.colsum_ws: Optional[torch.Tensor] = None      # row-segment partials of the bias-gradient column sums
         self.tuning = False
         self.tuned: Dict[tuple, Tuple[int, int]] = {}
@@ -514,7 +515,7 @@ class ConvLayer:
         elif self.name in self.ws.tuned_wgrad:
             self.wgrad_split, self._wgrad_tuned = self.ws.tuned_wgrad[self.name], True
         else:
-            self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU + tiles - 1) // tiles, max(nk // 8, 1), 192))
+            self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU) // tiles, max(nk // 8, 1), 192))   # <= 768 resident WGs
         if self.gpack is not None and self.n_slots * self.wgrad_split == 1:
             self.wgrad_slab = self.gpack.view(1, self.Co, self.Kf)
         else:
@@ -534,6 +535,7 @@ class ConvLayer:
         d.g_H, d.g_W, d.n_img = dy.H, dy.W, dy.B
         d.y, d.y_ld, d.N = dy.ptr, dy.ld, self.Co
         d.split_k, d.dtype = split, self.ws.code
+        d.stages = self.ws.wgrad_stages
         d.slab = slab_ptr
         d.x_bytes, d.w_bytes = x.bytes_left, dy.bytes_left          # w_bytes carries the dy extent in WGRAD mode
         return d
