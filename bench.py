@@ -65,7 +65,7 @@ def cpu_baseline(B, size, steps, seed):
         log(f"cpu baseline step {i}: {time.perf_counter() - t0:.2f} s")
         if i > 0:
             times.append(time.perf_counter() - t0)
-        if i >= 1 and sum(times) > 40:      # bounded sample
+        if i >= 1 and sum(times) > 25:      # bounded sample
             break
     med = sorted(times)[len(times) // 2]
     return {"value": B / med, "unit": "pairs/s", "cores": cores, "kind": "port",
@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--no-3d", action="store_true", help="skip the 128^3 affmodel leg")
     ap.add_argument("--tune-cache", default=None, help="JSON of measured launch shapes (written after tuning, reused when present)")
     ap.add_argument("--no-autotune", action="store_true", help="heuristic launch shapes (counter-collection runs: the tuning pass is slow there)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=20)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
