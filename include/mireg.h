@@ -99,6 +99,12 @@ int mireg_tail_bwd(const mireg_tail_job* jobs_dev, int njobs, int total_blocks, 
  * align_corners=False); planar (B,C,D,H,W) fp32 volumes, theta (B,3,4) ---------------------------------- */
 int mireg_affine_sample3d(const float* vol, const float* theta, float* out, int B, int C, int D, int H, int W,
                           hipStream_t stream);
+/* autograd of the above with respect to theta (the `para` output of affmodel, models.py:184-188):
+ * gtheta[B][12] (+)= d/d theta of sum(gout * out).  workspace: B * MIREG_AFFINE3D_BWD_BLOCKS * 12 floats; two-stage,
+ * fixed-order reduction (deterministic).  The moving volume is an input of the model, not a parameter: no d/d vol. */
+#define MIREG_AFFINE3D_BWD_BLOCKS 512
+int mireg_affine_sample3d_bwd(const float* vol, const float* theta, const float* gout, float* gtheta, float* workspace,
+                              int accumulate, int B, int C, int D, int H, int W, hipStream_t stream);
 
 /* ---- K14/K15: models.py:286 (rint + clip 0..3, on device), utils.py:72-91 (Dice) --------- */
 int mireg_seg_round(const float* in, float* out, long n, hipStream_t stream);
@@ -146,7 +152,10 @@ typedef struct mireg_conv_desc {
   long slab_cls_stride;    /* floats between the split-K slabs of consecutive classes */
   /* optional depth axis for Conv3d (reference models.py:39-43,160-165), NDHWC volumes; all zero for 2-D launches:
    * iz = gz*mul_z + off_z + tz*step_z in [0, x_D); rows run over (n_img, g_D, g_H, g_W); k = ((tz*taps_y+ty)*taps_x+tx)*x_C + c;
-   * output voxel z = gz*y_mul_z + y_off_z in a y_D deep volume.  mireg_conv_gemm only (single class). */
+   * output voxel z = gz*y_mul_z + y_off_z in a y_D deep volume.  mireg_conv_gemm: single class (the host issues one
+   * launch per output-voxel parity class for the backward-data form).  mireg_conv_wgrad: one launch per depth tap tz
+   * (taps_z must be 0/1, off_z = the tap's source-slice offset), each writing its [Cout][taps_y*taps_x*x_C] column
+   * block of a slab whose rows are slab_ld floats apart. */
   int x_D, taps_z, mul_z, off_z, step_z, g_D, y_D, y_mul_z, y_off_z;
   /* output-column tile width of mireg_conv_gemm: 0 = by N (128 / 64 / 32); 64 or 128 forces it (the host picks the
    * width whose tile count fills the 256 CUs most evenly) */
@@ -154,6 +163,9 @@ typedef struct mireg_conv_desc {
   /* mireg_conv_wgrad: LDS ring depth.  0 / 3 = three stages (48 KiB: three workgroups per CU, best stand-alone and when the
    * wgrad stream is the long pole); 4 = four stages (64 KiB: two per CU, leaves more of each CU to the concurrent main chain) */
   int stages;
+  /* mireg_conv_wgrad: floats between consecutive Cout rows of the slab (0 = taps_y*taps_x*x_C); split-K slabs are
+   * N*slab_ld apart */
+  long slab_ld;
 } mireg_conv_desc;
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream);
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);

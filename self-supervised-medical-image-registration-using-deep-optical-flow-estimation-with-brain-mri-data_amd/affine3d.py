@@ -4,7 +4,9 @@
 Conv3d + ReLU run on the same LDS-DMA implicit-GEMM kernel as the 2-D predictors (depth axis in the descriptor,
 NDHWC volumes), the Linear layer is the same kernel with the whole remaining volume as one tap window, the
 affine grid + trilinear sampling is one fused kernel, and `Affloss` reuses the moment / finalize kernels of
-OFEloss.  Forward / evaluation only in this round (no 3-D backward kernels yet).
+OFEloss.  Training: both are torch.autograd functions whose backward runs on the same kernels -- backward-data as one
+GEMM launch per output-voxel parity class, backward-weights as one launch per depth tap into a shared slab, the ReLU
+masks, the bias column sums, the sampler's d/d theta kernel and the Charbonnier / NCC gradient of OFEloss.
 `fc_in` defaults to the reference's hard-wired 176*512 (256x256x176 volumes); pass the flattened size of
 conv6's output for other volume sizes.
 """
@@ -64,21 +66,128 @@ class Conv3dLayer:
         d.y_mul_z = d.y_mul_y = d.y_mul_x = 1
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         d.slope, d.dtype, d.split_k = slope, self.ws.code, 1
-        M, bn = B * Do * Ho * Wo, (128 if self.Co > 64 else (64 if self.Co > 32 else 32))
-        tiles = ((M + 127) // 128) * ((self.Co + bn - 1) // bn)
-        nk = (self.Kf + 31) // 32
+        self._launch(d, B * Do * Ho * Wo, self.Co, self.Kf)
+        return Do, Ho, Wo
+
+    def _launch(self, d: ConvDesc, M: int, N: int, K: int) -> None:
+        bn = 128 if N > 64 else (64 if N > 32 else 32)
+        tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
+        nk = (K + 31) // 32
+        d.split_k = 1
         if tiles < 256 and nk >= 16:                        # deep / tiny layers (incl. the Linear): split K
             split = max(1, min((512 + tiles - 1) // tiles, nk // 4, 64))
             if split > 1:
-                d.split_k, d.slab_cls_stride = split, split * M * self.Co
-                self.ws.need_scratch(split * M * self.Co)
+                d.split_k, d.slab_cls_stride = split, split * M * N
+                self.ws.need_scratch(split * M * N)
                 d.slab = self.ws.get_scratch().data_ptr()
         _lib.call("mireg_conv_gemm", ctypes.byref(d), _stream())
-        return Do, Ho, Wo
+
+    # ---- backward (autograd of nn.Conv3d, reference models.py:39-43 trained through loss.backward()) ----
+    def dgrad_classes(self) -> list:
+        """Per output-voxel parity class (pz, py, px) of the backward-data form: the taps t = r + s*j that reach it, packed
+        [Ci][(jz, jy, jx)][Cop] (host-side slicing of the fp32 weight; a few small tensors per step)."""
+        W = self.weight.detach().float()
+        Cop = rup(self.Co, 8)
+        out = []
+        for pz in range(self.stride[0]):
+            for py in range(self.stride[1]):
+                for px in range(self.stride[2]):
+                    par = (pz, py, px)
+                    r = [(par[a] + self.pad[a]) % self.stride[a] for a in range(3)]
+                    c = [(par[a] + self.pad[a]) // self.stride[a] for a in range(3)]
+                    sub = W[:, :, r[0]::self.stride[0], r[1]::self.stride[1], r[2]::self.stride[2]]
+                    nt = tuple(sub.shape[2:])
+                    if min(nt) == 0:
+                        raise ValueError("Conv3d kernel smaller than its stride is not supported")
+                    pk = torch.zeros(self.Ci, nt[0] * nt[1] * nt[2], Cop, device=W.device, dtype=self.ws.dtype)
+                    pk[:, :, :self.Co] = sub.permute(1, 2, 3, 4, 0).reshape(self.Ci, -1, self.Co)
+                    out.append(dict(par=par, c=c, nt=nt, pack=pk.view(self.Ci, -1)))
+        return out
+
+    def dgrad(self, gy: torch.Tensor, odims: Tuple[int, int, int], gx: torch.Tensor, idims: Tuple[int, int, int]) -> None:
+        """gx[(z,y,x), ci] = sum_{taps, co} gy[(z + p - t)/s ..., co] W[co][ci][t]; one GEMM launch per parity class."""
+        B = gy.shape[0]
+        Cop = rup(self.Co, 8)
+        self._keep = self.dgrad_classes()
+        for k in self._keep:
+            g = [(idims[a] - k["par"][a] + self.stride[a] - 1) // self.stride[a] for a in range(3)]
+            if min(g) <= 0:
+                continue
+            d = ConvDesc()
+            d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = gy.data_ptr(), gy.shape[-1], odims[0], odims[1], odims[2], Cop
+            d.taps_z, d.taps_y, d.taps_x = k["nt"]
+            d.mul_z = d.mul_y = d.mul_x = 1
+            d.off_z, d.off_y, d.off_x = k["c"]
+            d.step_z = d.step_y = d.step_x = -1
+            d.g_D, d.g_H, d.g_W, d.n_img = g[0], g[1], g[2], B
+            d.w, d.w_ld, d.N = k["pack"].data_ptr(), k["pack"].shape[1], self.Ci
+            d.x_bytes, d.w_bytes = gy.numel() * gy.element_size(), k["pack"].numel() * k["pack"].element_size()
+            d.y, d.y_ld, d.y_D, d.y_H, d.y_W = gx.data_ptr(), gx.shape[-1], idims[0], idims[1], idims[2]
+            d.y_mul_z, d.y_mul_y, d.y_mul_x = self.stride
+            d.y_off_z, d.y_off_y, d.y_off_x = k["par"]
+            d.slope, d.dtype = 1.0, self.ws.code
+            self._launch(d, B * g[0] * g[1] * g[2], self.Ci, k["pack"].shape[1])
+
+    def wgrad(self, x: torch.Tensor, idims: Tuple[int, int, int], gy: torch.Tensor, odims: Tuple[int, int, int]) -> None:
+        """slab[z][co][(tz,ty,tx)*Cip + ci] = sum_voxels gy[v][co] x[v @ tap][ci]: one backward-weights launch per depth tap,
+        each filling its column block of the shared slab (mireg_conv_desc.slab_ld)."""
+        B = x.shape[0]
+        P = B * odims[0] * odims[1] * odims[2]
+        K2 = self.kh * self.kw * self.Cip
+        tiles = ((self.Co + 127) // 128) * ((K2 + 127) // 128)            # per launch (the depth taps run back to back)
+        nk = (P + 31) // 32
+        split = 1 if tiles >= 256 else max(1, min(768 // tiles, max(nk // 8, 1), 192))
+        if getattr(self, "slab", None) is None or self.slab.shape[0] != split:
+            self.slab = torch.zeros(split, self.Co, self.Kf, device=x.device, dtype=torch.float32)
+        for tz in range(self.kd):
+            d = ConvDesc()
+            d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = x.data_ptr(), x.shape[-1], idims[0], idims[1], idims[2], self.Cip
+            d.taps_y, d.taps_x = self.kh, self.kw
+            d.mul_z, d.mul_y, d.mul_x = self.stride
+            d.off_z, d.off_y, d.off_x = tz - self.pad[0], -self.pad[1], -self.pad[2]
+            d.step_y = d.step_x = 1
+            d.g_D, d.g_H, d.g_W, d.n_img = odims[0], odims[1], odims[2], B
+            d.y, d.y_ld, d.N = gy.data_ptr(), gy.shape[-1], self.Co
+            d.split_k, d.dtype, d.stages = split, self.ws.code, 3
+            d.slab, d.slab_ld = self.slab.data_ptr() + 4 * tz * K2, self.Kf
+            d.x_bytes, d.w_bytes = x.numel() * x.element_size(), gy.numel() * gy.element_size()
+            _lib.call("mireg_conv_wgrad", ctypes.byref(d), _stream())
+
+    def unpack_job(self, grad: torch.Tensor) -> PackJob:
+        j = PackJob()
+        j.src, j.dst = self.slab.data_ptr(), grad.data_ptr()
+        j.Co, j.Ci, j.kh, j.kw = self.Co, self.Ci, self.kd * self.kh, self.kw
+        j.Cpad, j.Cop, j.ld, j.stride, j.nclass = self.Cip, rup(self.Co, 8), self.Kf, 1, 0
+        j.nsplit, j.accumulate = self.slab.shape[0], 0
+        return j
+
+    def bias_grad(self, gy: torch.Tensor, out: torch.Tensor) -> None:
+        ws = self.ws
+        if ws.colsum_ws is None or ws.colsum_ws.numel() < 64 * max(self.Co, 1024):
+            ws.colsum_ws = torch.empty(64 * max(self.Co, 1024), device=ws.device, dtype=torch.float32)
+        M = gy.numel() // gy.shape[-1]
+        _lib.call("mireg_colsum", gy.data_ptr(), gy.shape[-1], M, self.Co, out.data_ptr(), 0, ws.colsum_ws.data_ptr(),
+                  ws.code, _stream())
+
+
+class _AffmodelFn(torch.autograd.Function):
+    """(x, *parameters) -> (para, warped); backward hands autograd the parameter gradients of the HIP backward pass."""
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        ctx.mod = mod
+        para, warped = mod._forward_impl(x, keep=True)
+        return para, warped
+
+    @staticmethod
+    def backward(ctx, g_para, g_warped):
+        return (None, None, *ctx.mod._backward_impl(g_para, g_warped))
 
 
 class affmodel(nn.Module):
-    """Drop-in for reference models.affmodel (forward only)."""
+    """Drop-in for reference models.affmodel: forward `(x) -> (para, warped)`; trains through loss.backward() with the
+    parameter gradients produced by the HIP backward pass (one forward in flight per module: the engine owns the saved
+    activations)."""
 
     def __init__(self, fc_in: int = 176 * 512, precision: str = "bf16"):
         super().__init__()
@@ -89,6 +198,14 @@ class affmodel(nn.Module):
         self.flat = nn.Flatten()
         self.fc = nn.Linear(fc_in, 12)
         self._eng: Dict[tuple, dict] = {}
+        self._last = None
+
+    def _params(self):
+        out = []
+        for i in range(1, 7):
+            conv = getattr(self, f"conv{i}")[0]
+            out += [conv.weight, conv.bias]
+        return out + [self.fc.weight, self.fc.bias]
 
     def _engine(self, x: torch.Tensor) -> dict:
         dtype = torch.bfloat16 if self.precision == "bf16" else torch.float32
@@ -98,12 +215,13 @@ class affmodel(nn.Module):
         self._eng.clear()
         B, C, D, H, W = x.shape
         ws = Workspace(x.device, dtype)
-        layers, bufs, dims = [], [], (D, H, W)
+        layers, bufs, dims, dlist = [], [], (D, H, W), [(D, H, W)]
         for i in range(1, 7):
             conv = getattr(self, f"conv{i}")[0]
             lay = Conv3dLayer(conv.weight, conv.bias, tuple(conv.stride), tuple(conv.padding), ws)
             layers.append(lay)
             dims = lay.out_dims(*dims)
+            dlist.append(dims)
             bufs.append(torch.zeros(B, *dims, rup(lay.Co, 8), device=x.device, dtype=dtype))
         if 512 * dims[0] * dims[1] * dims[2] != self.fc.in_features:
             raise RuntimeError(f"affmodel: fc expects {self.fc.in_features} features, conv6 yields 512x{dims} = "
@@ -111,7 +229,7 @@ class affmodel(nn.Module):
         # Linear == Conv3d whose single tap window is the whole conv6 volume; torch flattens (C, D, H, W)
         fcw = self.fc.weight.view(12, 512, *dims)
         fc = Conv3dLayer(fcw, self.fc.bias, (1, 1, 1), (0, 0, 0), ws)
-        e = dict(ws=ws, layers=layers, bufs=bufs, fc=fc, fc_dims=dims,
+        e = dict(ws=ws, layers=layers, bufs=bufs, fc=fc, fc_dims=dims, dims=dlist,
                  x0=torch.zeros(B, D, H, W, 8, device=x.device, dtype=dtype),
                  para=torch.zeros(B, 1, 1, 1, 16, device=x.device, dtype=torch.float32),
                  paraT=torch.zeros(B, 1, 1, 1, 16, device=x.device, dtype=dtype))
@@ -122,11 +240,14 @@ class affmodel(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("mireg.affmodel runs on the MI355X only; there is no CPU fallback")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("affmodel training (3-D backward kernels) is not implemented yet; use torch.no_grad()")
+            return _AffmodelFn.apply(self, x, *self._params())
+        return self._forward_impl(x, keep=False)
+
+    def _forward_impl(self, x: torch.Tensor, keep: bool):
         e = self._engine(x)
         ws, st = e["ws"], _stream()
         B, C, D, H, W = x.shape
-        x = x.float().contiguous()
+        x = x.detach().float().contiguous()
         jobs = [l.pack_job() for l in e["layers"]] + [e["fc"].pack_job()]
         units, dunits = assign_tiles(jobs, False)
         tab = upload_table(jobs, x.device)
@@ -142,30 +263,96 @@ class affmodel(nn.Module):
         moving = x[:, 1:].contiguous()
         warped = torch.empty_like(moving)
         _lib.call("mireg_affine_sample3d", moving.data_ptr(), para.data_ptr(), warped.data_ptr(), B, 1, D, H, W, st)
+        self._last = dict(e=e, moving=moving, para=para, shape=(B, D, H, W)) if keep else None
         return para, warped
+
+    def _backward_impl(self, g_para, g_warped):
+        """d loss / d parameters in the order of `_params()` (autograd of reference models.py:182-191)."""
+        if self._last is None:
+            raise RuntimeError("affmodel backward without a saved forward (one forward in flight per module)")
+        L, self._last = self._last, None
+        e, (B, D, H, W) = L["e"], L["shape"]
+        ws, st, dev = e["ws"], _stream(), L["moving"].device
+        layers, bufs, dl, fc = e["layers"], e["bufs"], e["dims"], e["fc"]
+        if "g" not in e:
+            e["g"] = [torch.zeros_like(b) for b in bufs]
+            e["gparaT"] = torch.zeros(B, 1, 1, 1, 16, device=dev, dtype=ws.dtype)
+            e["aff_ws"] = torch.empty(B * 512 * 12, device=dev, dtype=torch.float32)
+        gtheta = (g_para.reshape(B, 12).float().clone() if g_para is not None
+                  else torch.zeros(B, 12, device=dev, dtype=torch.float32)).contiguous()
+        if g_warped is not None:
+            gw = g_warped.float().contiguous()
+            _lib.call("mireg_affine_sample3d_bwd", L["moving"].data_ptr(), L["para"].data_ptr(), gw.data_ptr(),
+                      gtheta.data_ptr(), e["aff_ws"].data_ptr(), 1, B, 1, D, H, W, st)
+        gp = e["gparaT"]
+        _lib.call("mireg_cast_from_f32", gp.data_ptr(), 16, gtheta.data_ptr(), 12, B, 12, 1.0, 0.0, ws.code, st)
+        params = self._params()
+        grads = [torch.zeros_like(p, dtype=torch.float32) for p in params]
+        one = (1, 1, 1)
+        fc.wgrad(bufs[5], dl[6], gp, one)
+        fc.bias_grad(gp, grads[13])
+        fc.dgrad(gp, one, e["g"][5], dl[6])
+        for i in range(5, -1, -1):
+            g, lay = e["g"][i], layers[i]
+            _lib.call("mireg_lrelu_bwd", g.data_ptr(), g.shape[-1], bufs[i].data_ptr(), bufs[i].shape[-1],
+                      g.numel() // g.shape[-1], lay.Co, 0.0, ws.code, st)                  # ReLU mask of this layer's output
+            xin = bufs[i - 1] if i > 0 else e["x0"]
+            lay.wgrad(xin, dl[i], g, dl[i + 1])
+            lay.bias_grad(g, grads[2 * i + 1])
+            if i > 0:
+                lay.dgrad(g, dl[i + 1], e["g"][i - 1], dl[i])
+        jobs = [layers[i].unpack_job(grads[2 * i]) for i in range(6)] + [fc.unpack_job(grads[12])]
+        units, _ = assign_tiles(jobs, True)
+        tab = upload_table(jobs, dev)
+        _lib.call("mireg_unpack_wgrad", tab.data_ptr(), len(jobs), units, st)
+        e["_tab"] = tab
+        return [g.to(p.dtype) for g, p in zip(grads, params)]
+
+
+class _AfflossFn(torch.autograd.Function):
+    """out4 = (gamma * photometric_3d, lamb_da * ncc_3d, 0, sum) as float64; backward = d/d warped (loss.py:16-19,38-50)."""
+
+    @staticmethod
+    def forward(ctx, warped, fixed, lamb_da, gamma):
+        w, f = warped.detach().float().contiguous(), fixed.detach().float().contiguous()
+        B, n = w.shape[0], w.numel()
+        sums = torch.zeros(1, SLOTS, 8, device=w.device, dtype=torch.float64)
+        npix = torch.tensor([n], dtype=torch.int64, device=w.device)
+        out = torch.empty(4, device=w.device, dtype=torch.float64)
+        st = _stream()
+        _lib.call("mireg_loss_partials", w.data_ptr(), f.data_ptr(), sums.data_ptr(), n, st)
+        # OFE finalisation with one scale: weight 0.05 -> fold 1/0.05 into gamma / zeta
+        _lib.call("mireg_ofe_finalize", sums.data_ptr(), npix.data_ptr(), 1, B, 0.0, gamma / 0.05, lamb_da / 0.05, out.data_ptr(), st)
+        ctx.saved = (w, f, sums, npix, B, n, lamb_da, gamma, warped.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g4):
+        w, f, sums, npix, B, n, lamb_da, gamma, dt = ctx.saved
+        st = _stream()
+        g4 = g4.to(torch.float64).contiguous()
+        coef = torch.empty(8, device=w.device, dtype=torch.float32)
+        gw = torch.empty_like(w)
+        _lib.call("mireg_ofe_bwd_coef", sums.data_ptr(), npix.data_ptr(), 1, B, 0.0, gamma / 0.05, lamb_da / 0.05,
+                  g4.data_ptr(), coef.data_ptr(), st)
+        _lib.call("mireg_loss_bwd", w.data_ptr(), f.data_ptr(), coef.data_ptr(), gw.data_ptr(), n, st)
+        return gw.to(dt), None, None, None
 
 
 def Affloss(warped: torch.Tensor, fixed: torch.Tensor, lamb_da: float = 1.0, gamma: float = 1.0):
-    """Drop-in for reference loss.Affloss (loss.py:87-94): (gamma * photometric_3d, lamb_da * ncc_3d, sum)."""
+    """Drop-in for reference loss.Affloss (loss.py:87-94): (gamma * photometric_3d, lamb_da * ncc_3d, sum); differentiable
+    with respect to `warped`."""
     if not warped.is_cuda:
         raise RuntimeError("mireg.Affloss runs on the MI355X only; there is no CPU fallback")
-    w, f = warped.float().contiguous(), fixed.float().contiguous()
-    B, n = w.shape[0], w.numel()
-    sums = torch.zeros(1, SLOTS, 8, device=w.device, dtype=torch.float64)
-    npix = torch.tensor([n], dtype=torch.int64, device=w.device)
-    out = torch.empty(4, device=w.device, dtype=torch.float64)
-    st = _stream()
-    _lib.call("mireg_loss_partials", w.data_ptr(), f.data_ptr(), sums.data_ptr(), n, st)
-    # OFE finalisation with one scale: weight 0.05 -> fold 1/0.05 into gamma / zeta
-    _lib.call("mireg_ofe_finalize", sums.data_ptr(), npix.data_ptr(), 1, B, 0.0, gamma / 0.05, lamb_da / 0.05, out.data_ptr(), st)
+    out = _AfflossFn.apply(warped, fixed, float(lamb_da), float(gamma))
     return out[0], out[1], out[0] + out[1]
 
 
 def photometric_loss_3d(fixed: torch.Tensor, warped: torch.Tensor):
-    """Drop-in for reference loss.photometric_loss_3d (loss.py:16-19) -- value only."""
+    """Drop-in for reference loss.photometric_loss_3d (loss.py:16-19)."""
     return Affloss(warped, fixed, 1.0, 1.0)[0]
 
 
 def correlation_loss_3d(fixed: torch.Tensor, warped: torch.Tensor):
-    """Drop-in for reference loss.correlation_loss_3d (loss.py:38-50) -- value only."""
+    """Drop-in for reference loss.correlation_loss_3d (loss.py:38-50)."""
     return Affloss(warped, fixed, 1.0, 1.0)[1]

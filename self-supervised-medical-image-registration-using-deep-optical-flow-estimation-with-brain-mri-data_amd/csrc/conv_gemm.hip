@@ -683,7 +683,10 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int gHW = p.g_H * p.g_W;
-  const int P = p.n_img * gHW;                                   // reduction length (pixels)
+  // Conv3d: one launch per depth tap; an "image" is then one (volume, output slice) pair whose source slice is
+  // gz*mul_z + off_z of an x_D deep volume (2-D launches: gD = xD = mulz = 1, off_z = 0)
+  const int gD = max(p.g_D, 1), xD = max(p.x_D, 1), mulz = max(p.mul_z, 1);
+  const int P = p.n_img * gD * gHW;                              // reduction length (pixels)
   const int nk_total = (P + BK - 1) / BK;
   int kt_begin = 0, kt_end = nk_total;
   if (p.split_k > 1) {
@@ -717,7 +720,7 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   const unsigned STEPX = (unsigned)p.mul_x * PIXB, ROWB_X = (unsigned)p.x_W * PIXB, STEPY = (unsigned)p.mul_y * ROWB_X;
   const unsigned IMGB = (unsigned)p.x_H * ROWB_X;
   const unsigned y_ldb = (unsigned)p.y_ld * sz;
-  int pix[2], p_gy[2], p_gx[2], s_iy[2], s_ix[2];
+  int pix[2], p_gy[2], p_gx[2], s_iy[2], s_ix[2], p_gz[2], s_iz[2];
   unsigned a_off[2], b_off[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -729,8 +732,11 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
     p_gx[c] = rem - p_gy[c] * p.g_W + (pix[c] - pp);            // a tail overshoot stays on the x axis (never used: pok)
     s_iy[c] = p_gy[c] * p.mul_y + b_dy;
     s_ix[c] = p_gx[c] * p.mul_x + b_dx;
+    const int vol = img / gD;
+    p_gz[c] = img - vol * gD;
+    s_iz[c] = p_gz[c] * mulz + p.off_z;
     a_off[c] = (unsigned)pix[c] * y_ldb + (unsigned)a_col * sz;
-    b_off[c] = (unsigned)img * IMGB + (unsigned)(s_iy[c] * (int)ROWB_X) + (unsigned)(s_ix[c] * (int)PIXB) + (unsigned)b_ch * sz;
+    b_off[c] = (unsigned)((vol * xD + s_iz[c]) * (int)IMGB) + (unsigned)(s_iy[c] * (int)ROWB_X) + (unsigned)(s_ix[c] * (int)PIXB) + (unsigned)b_ch * sz;
   }
 
   auto issue = [&](int stage) {
@@ -741,7 +747,7 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
       const bool pok = pix[c] < P;
       const unsigned aoff = (pok && a_cok) ? a_off[c] : kOOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_void_t)(At + (wid + 4 * c) * 1024), 16, aoff, 0, 0, 0);
-      const bool bok = pok && b_cok && (unsigned)s_iy[c] < (unsigned)p.x_H && (unsigned)s_ix[c] < (unsigned)p.x_W;
+      const bool bok = pok && b_cok && (unsigned)s_iy[c] < (unsigned)p.x_H && (unsigned)s_ix[c] < (unsigned)p.x_W && (unsigned)s_iz[c] < (unsigned)xD;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t)(Bt + (wid + 4 * c) * 1024), 16, bok ? b_off[c] : kOOB, 0, 0, 0);
       pix[c] += BK;
       a_off[c] += BK * y_ldb;
@@ -756,7 +762,13 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
         if (++p_gy[c] == p.g_H) {
           p_gy[c] = 0;
           s_iy[c] -= p.g_H * p.mul_y;
-          b_off[c] += IMGB - (unsigned)p.g_H * STEPY;
+          b_off[c] += (unsigned)mulz * IMGB - (unsigned)p.g_H * STEPY;
+          s_iz[c] += mulz;
+          if (++p_gz[c] == gD) {                                    // next volume
+            p_gz[c] = 0;
+            s_iz[c] -= gD * mulz;
+            b_off[c] += (unsigned)(xD - gD * mulz) * IMGB;
+          }
         }
       }
     }
@@ -851,7 +863,8 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   __syncthreads();
   float* ct = reinterpret_cast<float*>(smem);
   const int Cout = p.N;
-  float* __restrict__ slab = p.slab + (long)blockIdx.z * Cout * Ktot;
+  const long sld = p.slab_ld > 0 ? p.slab_ld : Ktot;               // Conv3d: the depth taps share one [Cout][taps_z*Ktot] slab
+  float* __restrict__ slab = p.slab + (long)blockIdx.z * Cout * sld;
   const bool vec = (Ktot % 4) == 0;
   for (int hp = 0; hp < 2; ++hp) {                                  // rows [64 hp, 64 hp + 64) of the tile
     if (hp) __syncthreads();
@@ -870,7 +883,7 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
       const int m = m0 + hp * WTM + mr, n = n0 + nl;
       if (m >= Cout || n >= Ktot) continue;
       const float4 v = *reinterpret_cast<const float4*>(ct + mr * BN + nl);
-      float* d = slab + (long)m * Ktot + n;
+      float* d = slab + (long)m * sld + n;
       if (vec) stg_u4(d, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
       else { const float vv[4] = {v.x, v.y, v.z, v.w}; for (int q = 0; q < 4 && n + q < Ktot; ++q) d[q] = vv[q]; }
     }
@@ -929,7 +942,8 @@ bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
   if (p->dtype != MIREG_DTYPE_BF16 && p->dtype != MIREG_DTYPE_F32) return false;
   if (p->x_C <= 0 || p->x_C % cpc || p->x_ld % cpc || ((uintptr_t)p->x % 16)) return false;
   if ((long)p->n_img * p->g_H * p->g_W * (p->g_D > 0 ? p->g_D : 1) >= (1L << 31)) return false;
-  if (wgrad && (p->g_D > 1 || p->taps_z > 1)) return false;                 // Conv3d backward-weights: not yet
+  if (wgrad && p->taps_z > 1) return false;                                 // Conv3d backward-weights: one launch per depth tap
+  if (wgrad && (p->g_D > 1 || p->x_D > 1) && !(p->x_bytes > 0 && p->w_bytes > 0 && p->x_bytes < (1L << 31) && p->w_bytes < (1L << 31))) return false;
   if (wgrad) {
     if (!p->y || !p->slab || p->y_ld % cpc || ((uintptr_t)p->y % 16)) return false;
   } else {

@@ -460,6 +460,69 @@ affine_sample3d_kernel(const float* __restrict__ vol, const float* __restrict__ 
   }
 }
 
+// d(loss)/d(theta) of the sampler above (autograd of models.py:187-188 with respect to `para`): per voxel the trilinear
+// weights' derivatives give d out / d (px, py, pz); px = ((gx + 1) W - 1)/2 and gx = theta[0, :] . (bx, by, bz, 1), so
+// gtheta[b][r][:] = sum_voxels (d/d p_r) * (extent_r / 2) * (bx, by, bz, 1).  Two stages, fixed order (deterministic):
+// block (blk, b) writes partial[b][blk][12]; the finalize adds them in double.
+__global__ void __launch_bounds__(kThreads)
+affine_sample3d_bwd_kernel(const float* __restrict__ vol, const float* __restrict__ theta, const float* __restrict__ gout,
+                           float* __restrict__ partial, int C, int D, int H, int W) {
+  __shared__ float red[12 * (kThreads / 64)];
+  const int b = blockIdx.y;
+  const long nvox = (long)D * H * W;
+  const float* t = theta + b * 12;
+  const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6], t7 = t[7], t8 = t[8], t9 = t[9],
+              t10 = t[10], t11 = t[11];
+  float acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((long)W * H));
+    const float bx = (2.f * x + 1.f) / (float)W - 1.f, by = (2.f * y + 1.f) / (float)H - 1.f, bz = (2.f * z + 1.f) / (float)D - 1.f;
+    const float gx = t0 * bx + t1 * by + t2 * bz + t3;
+    const float gy = t4 * bx + t5 * by + t6 * bz + t7;
+    const float gz = t8 * bx + t9 * by + t10 * bz + t11;
+    const float px = ((gx + 1.f) * (float)W - 1.f) / 2.f, py = ((gy + 1.f) * (float)H - 1.f) / 2.f, pz = ((gz + 1.f) * (float)D - 1.f) / 2.f;
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx1 = px - fx, wy1 = py - fy, wz1 = pz - fz;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float* src = vol + ((long)b * C + c) * nvox;
+      const float g = gout[((long)b * C + c) * nvox + v];
+      float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int xi = x0 + (k & 1), yi = y0 + ((k >> 1) & 1), zi = z0 + (k >> 2);
+        if (xi < 0 || xi >= W || yi < 0 || yi >= H || zi < 0 || zi >= D) continue;
+        const float s = src[((long)zi * H + yi) * W + xi];
+        const float wx = (k & 1) ? wx1 : 1.f - wx1, wy = ((k >> 1) & 1) ? wy1 : 1.f - wy1, wz = (k >> 2) ? wz1 : 1.f - wz1;
+        ax += ((k & 1) ? s : -s) * wy * wz;
+        ay += (((k >> 1) & 1) ? s : -s) * wx * wz;
+        az += ((k >> 2) ? s : -s) * wx * wy;
+      }
+      dx += g * ax; dy += g * ay; dz += g * az;
+    }
+    dx *= 0.5f * (float)W; dy *= 0.5f * (float)H; dz *= 0.5f * (float)D;
+    acc[0] += dx * bx; acc[1] += dx * by; acc[2] += dx * bz; acc[3] += dx;
+    acc[4] += dy * bx; acc[5] += dy * by; acc[6] += dy * bz; acc[7] += dy;
+    acc[8] += dz * bx; acc[9] += dz * by; acc[10] += dz * bz; acc[11] += dz;
+  }
+  block_sum<12>(acc, red);
+  if (threadIdx.x == 0) {
+    float* dst = partial + ((long)b * gridDim.x + blockIdx.x) * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dst[i] = acc[i];
+  }
+}
+
+__global__ void affine_sample3d_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ gtheta, int nblk,
+                                                    int accumulate) {
+  const int b = blockIdx.x, j = threadIdx.x;
+  if (j >= 12) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)partial[((long)b * nblk + k) * 12 + j];
+  gtheta[b * 12 + j] = (float)s + (accumulate ? gtheta[b * 12 + j] : 0.f);
+}
+
 // =============================================================================================
 // Multi-scale fused tail of the training step (reference train.py:50-52 + loss.py:66-84 over the six
 // flow scales): ONE launch per phase instead of one per scale and op.  Job i = scale i; virtual block
@@ -700,6 +763,17 @@ int mireg_affine_sample3d(const float* vol, const float* theta, float* out, int 
   MIREG_CHECK_ARG(vol && theta && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
   hipLaunchKernelGGL(affine_sample3d_kernel, dim3(grid_for((long)B * D * H * W)), dim3(kThreads), 0, stream, vol, theta, out, B, C, D, H, W);
   MIREG_LAUNCH_RET();
+}
+
+int mireg_affine_sample3d_bwd(const float* vol, const float* theta, const float* gout, float* gtheta, float* workspace,
+                              int accumulate, int B, int C, int D, int H, int W, hipStream_t stream) {
+  if (!vol || !theta || !gout || !gtheta || !workspace || B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return MIREG_ERR_ARG;
+  const long nvox = (long)D * H * W;
+  int nblk = (int)((nvox + kThreads - 1) / kThreads);
+  if (nblk > MIREG_AFFINE3D_BWD_BLOCKS) nblk = MIREG_AFFINE3D_BWD_BLOCKS;
+  hipLaunchKernelGGL(affine_sample3d_bwd_kernel, dim3(nblk, B), dim3(kThreads), 0, stream, vol, theta, gout, workspace, C, D, H, W);
+  hipLaunchKernelGGL(affine_sample3d_bwd_finalize_kernel, dim3(B), dim3(64), 0, stream, workspace, gtheta, nblk, accumulate);
+  return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
 }
 
 int mireg_tail_resize(const mireg_tail_job* jobs_dev, int njobs, int total_blocks, const float* x, int B, int H, int W,

@@ -50,7 +50,7 @@ class ConvDesc(ctypes.Structure):
                 ("n_cls", ctypes.c_int), ("cls", ConvCls * 4), ("slab_cls_stride", ctypes.c_long),
                 ("x_D", ctypes.c_int), ("taps_z", ctypes.c_int), ("mul_z", ctypes.c_int), ("off_z", ctypes.c_int),
                 ("step_z", ctypes.c_int), ("g_D", ctypes.c_int), ("y_D", ctypes.c_int), ("y_mul_z", ctypes.c_int),
-                ("y_off_z", ctypes.c_int), ("tile_n", ctypes.c_int), ("stages", ctypes.c_int)]
+                ("y_off_z", ctypes.c_int), ("tile_n", ctypes.c_int), ("stages", ctypes.c_int), ("slab_ld", ctypes.c_long)]
 
 
 class PackClass(ctypes.Structure):
