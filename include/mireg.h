@@ -106,6 +106,28 @@ int mireg_affine_sample3d(const float* vol, const float* theta, float* out, int 
 int mireg_affine_sample3d_bwd(const float* vol, const float* theta, const float* gout, float* gtheta, float* workspace,
                               int accumulate, int B, int C, int D, int H, int W, hipStream_t stream);
 
+/* ---- volume (3-D) counterparts of the registration tail: SURVEY section 8 row a14 / BASELINE config "3D FlowNetS on 128^3".
+ * The reference has no dense 3-D flow; these follow its 2-D conventions axis by axis (flow channel 0/1/2 = x/y/z):
+ *   resize  = F.interpolate(mode='trilinear', align_corners)      (models.py:258, loss.py:11, FlowNetS/FlowNetS.py:83)
+ *   stn3d   = sample frame at (i + flow_i)(n_i - 1)/n_i per axis, zeros outside (models.py:256-268); d/d flow only
+ *   smooth  = sum_c sum_axes charbonnier(f - f_shifted) / 3 / B   (loss.py:21-29 with three flow channels; the kernels
+ *             add 2/3 of the raw sum into the smoothness slot so mireg_ofe_finalize / mireg_ofe_bwd_coef serve unchanged)
+ * Volumes are planar fp32 (B,C,D,H,W); `in`/`gin` of the resize and every `flow` are addressed through element strides
+ * (batch, channel, voxel), so channel-last predictor outputs are read in place; gflow is planar (B,3,d,h,w).
+ * beta: 0 = overwrite, otherwise dst = dst*beta + value.  All backward kernels are gather-form (deterministic). */
+int mireg_resize_trilinear_fwd(const float* in, long isn, long isc, long isp, float* out, int N, int C, int D, int H, int W,
+                               int d, int h, int w, int align_corners, hipStream_t stream);
+int mireg_resize_trilinear_bwd(const float* gout, float* gin, long isn, long isc, long isp, int N, int C, int D, int H, int W,
+                               int d, int h, int w, int align_corners, float beta, hipStream_t stream);
+int mireg_stn3d_fwd(const float* flow, long fsb, long fsc, long fsp, const float* frame, float* warped, int B, int C, int d,
+                    int h, int w, hipStream_t stream);
+int mireg_stn3d_bwd(const float* flow, long fsb, long fsc, long fsp, const float* frame, const float* gout, float* gflow,
+                    float beta, int B, int C, int d, int h, int w, hipStream_t stream);
+int mireg_smoothness3d_fwd(const float* flow, long fsb, long fsc, long fsp, double* sum, int B, int d, int h, int w,
+                           hipStream_t stream);
+int mireg_smoothness3d_bwd(const float* flow, long fsb, long fsc, long fsp, const float* coef, float* gflow, float beta, int B,
+                           int d, int h, int w, hipStream_t stream);
+
 /* ---- K14/K15: models.py:286 (rint + clip 0..3, on device), utils.py:72-91 (Dice) --------- */
 int mireg_seg_round(const float* in, float* out, long n, hipStream_t stream);
 /* counts: workspace B*9 floats; dice[b] = mean_l 2|A_l & B_l| / (|A_l| + |B_l|), l = 1..3 */

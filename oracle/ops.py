@@ -207,6 +207,59 @@ def aff_loss(warped: torch.Tensor, fixed: torch.Tensor, lamb_da: float = 1.0, ga
 
 
 # ----------------------------------------------------------------------------
+# a14 / BASELINE config "3D FlowNetS on 128^3": dense 3-D flow.  The reference has no such path:
+# these are the reference's 2-D formulas written per axis, pinned at op level against torch's own 5-D ops
+# (F.interpolate trilinear, F.grid_sample) -- which is why, unlike the 2-D restatements above, they call them.
+# ----------------------------------------------------------------------------
+def resize_trilinear(x: torch.Tensor, size, align_corners: bool) -> torch.Tensor:
+    import torch.nn.functional as F
+    return F.interpolate(x, size=tuple(size), mode="trilinear", align_corners=align_corners)
+
+
+def stn3d(flow: torch.Tensor, frame: torch.Tensor) -> torch.Tensor:
+    """models.py:256-268 per axis: frame resized (align_corners=True) to the flow's size; grid = (flow + voxel index) *
+    (2/w, 2/h, 2/d) - 1; grid_sample(align_corners=True, zeros).  flow channels 0/1/2 = x/y/z displacement."""
+    import torch.nn.functional as F
+    B, _, d, h, w = flow.shape
+    frame_r = resize_trilinear(frame, (d, h, w), True) if tuple(frame.shape[2:]) != (d, h, w) else frame
+    zz, yy, xx = torch.meshgrid(torch.arange(d, dtype=F32), torch.arange(h, dtype=F32), torch.arange(w, dtype=F32), indexing="ij")
+    idx = torch.stack((xx, yy, zz), dim=-1).unsqueeze(0)                       # (1,d,h,w,3) in (x,y,z) order
+    grid = (flow.permute(0, 2, 3, 4, 1) + idx) * torch.tensor([2 / w, 2 / h, 2 / d], dtype=F32) - 1
+    return F.grid_sample(frame_r, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+
+
+def smoothness_loss_3d(flow: torch.Tensor) -> torch.Tensor:
+    """loss.py:21-29 with three axes and three channels: forward differences against a zero-extended copy, channel mean, / B."""
+    b = flow.shape[0]
+    s = 0
+    for ax in (2, 3, 4):
+        sh = torch.zeros_like(flow)
+        src = [slice(None)] * 5
+        dst = [slice(None)] * 5
+        src[ax], dst[ax] = slice(1, None), slice(0, -1)
+        sh[tuple(dst)] = flow[tuple(src)]
+        s = s + charbonnier(flow - sh)
+    return (s.sum(dim=1) / 3).sum() / b
+
+
+def ofe_loss_3d(flows: Sequence[torch.Tensor], warped: Sequence[torch.Tensor], fixed: torch.Tensor,
+                lamb_da: float = 0.5, gamma: float = 100.0, zeta: float = 100.0):
+    """loss.py:66-84 over volumes (fixed resized with trilinear align_corners=False, as loss.py:11,54 do in 2-D)."""
+    n = len(flows)
+    wts = torch.from_numpy(0.05 * np.arange(1, n + 1))
+    p = c = s = 0
+    for i in range(n):
+        fr = fixed if tuple(fixed.shape[2:]) == tuple(warped[i].shape[2:]) else resize_trilinear(fixed, warped[i].shape[2:], False)
+        p = p + wts[i] * photometric_loss_3d(fr, warped[i])
+        c = c + wts[i] * correlation_loss_3d(fr, warped[i])
+        s = s + wts[i] * smoothness_loss_3d(flows[i])
+    p = 1 / n * gamma * p
+    c = 1 / n * zeta * c
+    s = 1 / n * lamb_da * s
+    return p, c, s, p + s + c
+
+
+# ----------------------------------------------------------------------------
 # a13: segmentation warp + Dice
 # ----------------------------------------------------------------------------
 def seg_round(warped_seg: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,298 @@
+// volume_ops.hip -- the 3-D (volume) counterparts of the per-scale registration tail, SURVEY section 8 row a14 / BASELINE config
+// "3D FlowNetS on 128^3": the reference has no dense 3-D flow, so these follow its 2-D conventions axis by axis
+//   resize  : F.interpolate(mode='trilinear', align_corners=...)           (models.py:258 / loss.py:11 / FlowNetS.py:83 per axis)
+//   stn3d   : sample at (i + flow_i) (n_i - 1) / n_i per axis, zero padding  (models.py:256-268)
+//   smooth  : sum_c sum_axes charb(f - f_shifted) / C                        (loss.py:21-29 with C = 3 flow channels)
+// Planar fp32 volumes (B,C,D,H,W); flows are addressed through (sb, sc, sp) strides so the predictor's channel-last
+// outputs are read in place.  All backward kernels are gather-form (one thread per destination element, no atomics).
+#include "mireg_common.h"
+#include "../../include/mireg.h"
+
+using namespace mireg;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kSlots = MIREG_SUM_SLOTS;
+
+inline int grid_for(long work, int cap = 4096) {
+  long g = (work + kThreads - 1) / kThreads;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// same op order as ATen's area_pixel_compute_source_index (linear modes)
+__device__ __forceinline__ void src_coord(int dst, float scale, int align, int in_size, int& i0, int& i1, float& l1) {
+  float s = align ? (float)dst * scale : fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
+  i0 = min((int)s, in_size - 1);
+  i1 = min(i0 + 1, in_size - 1);
+  l1 = s - (float)i0;
+}
+
+__device__ __forceinline__ void out_range(int i, float scale, int align, int out_size, int& lo, int& hi) {
+  const float inv = scale > 0.f ? 1.f / scale : 0.f;
+  const float a = align ? ((float)i - 1.f) * inv : (((float)i - 1.f) + 0.5f) * inv - 0.5f;
+  const float b = align ? ((float)i + 1.f) * inv : (((float)i + 1.f) + 0.5f) * inv - 0.5f;
+  lo = max((int)floorf(a) - 1, 0);
+  hi = min((int)ceilf(b) + 1, out_size - 1);
+  if (scale <= 0.f) { lo = 0; hi = out_size - 1; }
+}
+
+inline float host_scale(int in, int out, int align) {
+  if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+
+// ---- trilinear resize -----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+resize3d_fwd_kernel(const float* __restrict__ in, long isn, long isc, long isp, float* __restrict__ out, int N, int C,
+                    int D, int H, int W, int d, int h, int w, float sz, float sy, float sx, int align) {
+  const long ovox = (long)d * h * w, total = (long)N * C * ovox;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w), y = (int)((i / w) % h), z = (int)((i / ((long)w * h)) % d);
+    const int c = (int)((i / ovox) % C), n = (int)(i / (ovox * C));
+    int z0, z1, y0, y1, x0, x1;
+    float lz, ly, lx;
+    src_coord(z, sz, align, D, z0, z1, lz);
+    src_coord(y, sy, align, H, y0, y1, ly);
+    src_coord(x, sx, align, W, x0, x1, lx);
+    const float* p = in + n * isn + c * isc;
+    auto at = [&](int zz, int yy, int xx) { return p[(((long)zz * H + yy) * W + xx) * isp]; };
+    const float a00 = at(z0, y0, x0) * (1.f - lx) + at(z0, y0, x1) * lx, a01 = at(z0, y1, x0) * (1.f - lx) + at(z0, y1, x1) * lx;
+    const float a10 = at(z1, y0, x0) * (1.f - lx) + at(z1, y0, x1) * lx, a11 = at(z1, y1, x0) * (1.f - lx) + at(z1, y1, x1) * lx;
+    const float b0 = a00 * (1.f - ly) + a01 * ly, b1 = a10 * (1.f - ly) + a11 * ly;
+    out[i] = b0 * (1.f - lz) + b1 * lz;
+  }
+}
+
+// gin[(Z,Y,X)] = sum over the output voxels whose taps include it; gin addressed through (isn, isc, isp)
+__global__ void __launch_bounds__(kThreads)
+resize3d_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, long isn, long isc, long isp, int N, int C,
+                    int D, int H, int W, int d, int h, int w, float sz, float sy, float sx, int align, float beta) {
+  const long ivox = (long)D * H * W, ovox = (long)d * h * w, total = (long)N * C * ivox;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W), Y = (int)((i / W) % H), Z = (int)((i / ((long)W * H)) % D);
+    const int c = (int)((i / ivox) % C), n = (int)(i / (ivox * C));
+    int zlo, zhi, ylo, yhi, xlo, xhi;
+    out_range(Z, sz, align, d, zlo, zhi);
+    out_range(Y, sy, align, h, ylo, yhi);
+    out_range(X, sx, align, w, xlo, xhi);
+    const float* g = gout + ((long)n * C + c) * ovox;
+    float acc = 0.f;
+    for (int z = zlo; z <= zhi; ++z) {
+      int z0, z1; float lz;
+      src_coord(z, sz, align, D, z0, z1, lz);
+      const float wz = (z0 == Z ? 1.f - lz : 0.f) + (z1 == Z ? lz : 0.f);
+      if (wz == 0.f) continue;
+      for (int y = ylo; y <= yhi; ++y) {
+        int y0, y1; float ly;
+        src_coord(y, sy, align, H, y0, y1, ly);
+        const float wy = (y0 == Y ? 1.f - ly : 0.f) + (y1 == Y ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int x = xlo; x <= xhi; ++x) {
+          int x0, x1; float lx;
+          src_coord(x, sx, align, W, x0, x1, lx);
+          const float wx = (x0 == X ? 1.f - lx : 0.f) + (x1 == X ? lx : 0.f);
+          if (wx != 0.f) acc += wz * wy * wx * g[((long)z * h + y) * w + x];
+        }
+      }
+    }
+    float* dst = gin + n * isn + c * isc + (((long)Z * H + Y) * W + X) * isp;
+    *dst = beta != 0.f ? *dst * beta + acc : acc;
+  }
+}
+
+// ---- dense 3-D warp ---------------------------------------------------------------------------------------------------
+// sampling coordinate per axis, same fp32 op order as the 2-D path: g = (i + f) * (2/n) - 1; p = ((g + 1)/2) * (n - 1)
+__device__ __forceinline__ float stn_coord(float pix, float disp, float two_over, float sizem1) {
+  const float g = (disp + pix) * two_over - 1.f;
+  return ((g + 1.f) / 2.f) * sizem1;
+}
+
+struct Taps3 {
+  int x0, y0, z0;
+  float wx1, wy1, wz1;
+};
+
+__device__ __forceinline__ Taps3 taps_for(const float* __restrict__ f, long fsc, int x, int y, int z, int d, int h, int w) {
+  const float two_w = (float)(2.0 / (double)w), two_h = (float)(2.0 / (double)h), two_d = (float)(2.0 / (double)d);
+  const float px = stn_coord((float)x, f[0], two_w, (float)(w - 1));
+  const float py = stn_coord((float)y, f[fsc], two_h, (float)(h - 1));
+  const float pz = stn_coord((float)z, f[2 * fsc], two_d, (float)(d - 1));
+  const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+  Taps3 t;
+  t.x0 = (int)fx; t.y0 = (int)fy; t.z0 = (int)fz;
+  t.wx1 = px - fx; t.wy1 = py - fy; t.wz1 = pz - fz;
+  return t;
+}
+
+__device__ __forceinline__ float tap3(const float* __restrict__ img, int x, int y, int z, int w, int h, int d) {
+  return (x >= 0 && x < w && y >= 0 && y < h && z >= 0 && z < d) ? img[((long)z * h + y) * w + x] : 0.f;
+}
+
+__global__ void __launch_bounds__(kThreads)
+stn3d_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, const float* __restrict__ frame,
+                 float* __restrict__ warped, int B, int C, int d, int h, int w) {
+  const long nvox = (long)d * h * w, total = (long)B * nvox;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / nvox);
+    const long v = i - (long)b * nvox;
+    const int x = (int)(v % w), y = (int)((v / w) % h), z = (int)(v / ((long)w * h));
+    const Taps3 t = taps_for(flow + b * fsb + v * fsp, fsc, x, y, z, d, h, w);
+    for (int c = 0; c < C; ++c) {
+      const float* img = frame + ((long)b * C + c) * nvox;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float wgt = ((k & 1) ? t.wx1 : 1.f - t.wx1) * (((k >> 1) & 1) ? t.wy1 : 1.f - t.wy1) * ((k >> 2) ? t.wz1 : 1.f - t.wz1);
+        acc += tap3(img, t.x0 + (k & 1), t.y0 + ((k >> 1) & 1), t.z0 + (k >> 2), w, h, d) * wgt;
+      }
+      warped[((long)b * C + c) * nvox + v] = acc;
+    }
+  }
+}
+
+// gflow planar (B,3,d,h,w): channel a = d/d flow_a = sum_c gout_c * d sample / d p_a * (n_a - 1)/n_a
+__global__ void __launch_bounds__(kThreads)
+stn3d_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, const float* __restrict__ frame,
+                 const float* __restrict__ gout, float* __restrict__ gflow, float beta, int B, int C, int d, int h, int w) {
+  const long nvox = (long)d * h * w, total = (long)B * nvox;
+  const float kx = (float)(w - 1) / (float)w, ky = (float)(h - 1) / (float)h, kz = (float)(d - 1) / (float)d;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / nvox);
+    const long v = i - (long)b * nvox;
+    const int x = (int)(v % w), y = (int)((v / w) % h), z = (int)(v / ((long)w * h));
+    const Taps3 t = taps_for(flow + b * fsb + v * fsp, fsc, x, y, z, d, h, w);
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float* img = frame + ((long)b * C + c) * nvox;
+      const float go = gout[((long)b * C + c) * nvox + v];
+      float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float s = tap3(img, t.x0 + (k & 1), t.y0 + ((k >> 1) & 1), t.z0 + (k >> 2), w, h, d);
+        const float wx = (k & 1) ? t.wx1 : 1.f - t.wx1, wy = ((k >> 1) & 1) ? t.wy1 : 1.f - t.wy1, wz = (k >> 2) ? t.wz1 : 1.f - t.wz1;
+        ax += ((k & 1) ? s : -s) * wy * wz;
+        ay += (((k >> 1) & 1) ? s : -s) * wx * wz;
+        az += ((k >> 2) ? s : -s) * wx * wy;
+      }
+      gx += go * ax; gy += go * ay; gz += go * az;
+    }
+    float* g = gflow + (long)b * 3 * nvox + v;
+    gx *= kx; gy *= ky; gz *= kz;
+    if (beta != 0.f) { g[0] = g[0] * beta + gx; g[nvox] = g[nvox] * beta + gy; g[2 * nvox] = g[2 * nvox] * beta + gz; }
+    else { g[0] = gx; g[nvox] = gy; g[2 * nvox] = gz; }
+  }
+}
+
+// ---- smoothness over three axes, three flow channels ------------------------------------------------------------------
+// the moment table's smoothness slot is finalised as sum / 2 (two flow channels in the reference); with three channels
+// the mean over channels is sum / 3, so the kernels carry the factor 2/3
+constexpr float kChan = 2.f / 3.f;
+
+__global__ void __launch_bounds__(kThreads)
+smooth3d_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, double* __restrict__ sum, int B, int d, int h, int w) {
+  __shared__ float red[kThreads / 64];
+  const long nvox = (long)d * h * w, total = (long)B * nvox;
+  float acc[1] = {0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / nvox);
+    const long v = i - (long)b * nvox;
+    const int x = (int)(v % w), y = (int)((v / w) % h), z = (int)(v / ((long)w * h));
+    const float* f = flow + b * fsb + v * fsp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float val = f[c * fsc];
+      const float nz = (z + 1 < d) ? f[c * fsc + (long)h * w * fsp] : 0.f;
+      const float ny = (y + 1 < h) ? f[c * fsc + (long)w * fsp] : 0.f;
+      const float nx = (x + 1 < w) ? f[c * fsc + fsp] : 0.f;
+      acc[0] += charb(val - nz) + charb(val - ny) + charb(val - nx);
+    }
+  }
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) atomicAdd(sum + (blockIdx.x % kSlots) * 8, (double)(acc[0] * kChan));
+}
+
+__global__ void __launch_bounds__(kThreads)
+smooth3d_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, const float* __restrict__ coef,
+                    float* __restrict__ gflow, float beta, int B, int d, int h, int w) {
+  const float cs = coef[5] * kChan;
+  const long nvox = (long)d * h * w, total = (long)B * nvox;
+  const long sz = (long)h * w * fsp, sy = (long)w * fsp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / nvox);
+    const long v = i - (long)b * nvox;
+    const int x = (int)(v % w), y = (int)((v / w) % h), z = (int)(v / ((long)w * h));
+    const float* f = flow + b * fsb + v * fsp;
+    float* g = gflow + (long)b * 3 * nvox + v;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* fc = f + c * fsc;
+      const float val = fc[0];
+      float acc = charb_grad(val - ((z + 1 < d) ? fc[sz] : 0.f)) + charb_grad(val - ((y + 1 < h) ? fc[sy] : 0.f)) +
+                  charb_grad(val - ((x + 1 < w) ? fc[fsp] : 0.f));
+      if (z > 0) acc -= charb_grad(fc[-sz] - val);
+      if (y > 0) acc -= charb_grad(fc[-sy] - val);
+      if (x > 0) acc -= charb_grad(fc[-fsp] - val);
+      acc *= cs;
+      g[c * nvox] = beta != 0.f ? g[c * nvox] * beta + acc : acc;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mireg_resize_trilinear_fwd(const float* in, long isn, long isc, long isp, float* out, int N, int C, int D, int H, int W,
+                               int d, int h, int w, int align_corners, hipStream_t stream) {
+  MIREG_CHECK_ARG(in && out && N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && d > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(resize3d_fwd_kernel, dim3(grid_for((long)N * C * d * h * w)), dim3(kThreads), 0, stream, in, isn, isc, isp, out,
+                     N, C, D, H, W, d, h, w, host_scale(D, d, align_corners), host_scale(H, h, align_corners),
+                     host_scale(W, w, align_corners), align_corners);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_resize_trilinear_bwd(const float* gout, float* gin, long isn, long isc, long isp, int N, int C, int D, int H, int W,
+                               int d, int h, int w, int align_corners, float beta, hipStream_t stream) {
+  MIREG_CHECK_ARG(gout && gin && N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && d > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(resize3d_bwd_kernel, dim3(grid_for((long)N * C * D * H * W)), dim3(kThreads), 0, stream, gout, gin, isn, isc,
+                     isp, N, C, D, H, W, d, h, w, host_scale(D, d, align_corners), host_scale(H, h, align_corners),
+                     host_scale(W, w, align_corners), align_corners, beta);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_stn3d_fwd(const float* flow, long fsb, long fsc, long fsp, const float* frame, float* warped, int B, int C, int d,
+                    int h, int w, hipStream_t stream) {
+  MIREG_CHECK_ARG(flow && frame && warped && B > 0 && C > 0 && d > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(stn3d_fwd_kernel, dim3(grid_for((long)B * d * h * w)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame,
+                     warped, B, C, d, h, w);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_stn3d_bwd(const float* flow, long fsb, long fsc, long fsp, const float* frame, const float* gout, float* gflow,
+                    float beta, int B, int C, int d, int h, int w, hipStream_t stream) {
+  MIREG_CHECK_ARG(flow && frame && gout && gflow && B > 0 && C > 0 && d > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(stn3d_bwd_kernel, dim3(grid_for((long)B * d * h * w)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame,
+                     gout, gflow, beta, B, C, d, h, w);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_smoothness3d_fwd(const float* flow, long fsb, long fsc, long fsp, double* sum, int B, int d, int h, int w,
+                           hipStream_t stream) {
+  MIREG_CHECK_ARG(flow && sum && B > 0 && d > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(smooth3d_fwd_kernel, dim3(grid_for((long)B * d * h * w, 1024)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp,
+                     sum, B, d, h, w);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_smoothness3d_bwd(const float* flow, long fsb, long fsc, long fsp, const float* coef, float* gflow, float beta, int B,
+                           int d, int h, int w, hipStream_t stream) {
+  MIREG_CHECK_ARG(flow && coef && gflow && B > 0 && d > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(smooth3d_bwd_kernel, dim3(grid_for((long)B * d * h * w)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, coef,
+                     gflow, beta, B, d, h, w);
+  MIREG_LAUNCH_RET();
+}
+
+}  // extern "C"
