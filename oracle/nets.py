@@ -292,6 +292,65 @@ class AffModel(nn.Module):
         return para, ops.affine_grid_sample_3d(moving, para)
 
 
+class FlowNetS3D(nn.Module):
+    """FlowNetS/FlowNetS.py:10-91 with 3-D modules and three flow channels (the reference has no 3-D predictor: this is the
+    build-side generalisation SURVEY section 8 a14 describes; pinned against torch's own Conv3d / BatchNorm3d / ConvTranspose3d)."""
+
+    def __init__(self, width_div: int = 1):
+        super().__init__()
+        c = [max(8, v // width_div) for v in (64, 128, 256, 512, 512, 1024)]
+        d = [max(8, v // width_div) for v in (512, 256, 128, 64)]
+
+        def conv(ci, co, k=3, s=1):
+            return nn.Sequential(nn.Conv3d(ci, co, k, s, (k - 1) // 2, bias=False), nn.BatchNorm3d(co), nn.LeakyReLU(0.1, inplace=True))
+
+        def deconv(ci, co):
+            return nn.Sequential(nn.ConvTranspose3d(ci, co, 4, 2, 1, bias=False), nn.LeakyReLU(0.1, inplace=True))
+
+        self.conv1, self.conv2, self.conv3 = conv(2, c[0], 7, 2), conv(c[0], c[1], 5, 2), conv(c[1], c[2], 5, 2)
+        self.conv3_1 = conv(c[2], c[2])
+        self.conv4, self.conv4_1 = conv(c[2], c[3], 3, 2), conv(c[3], c[3])
+        self.conv5, self.conv5_1 = conv(c[3], c[4], 3, 2), conv(c[4], c[4])
+        self.conv6, self.conv6_1 = conv(c[4], c[5], 3, 2), conv(c[5], c[5])
+        cat5, cat4, cat3, cat2 = c[4] + d[0] + 3, c[3] + d[1] + 3, c[2] + d[2] + 3, c[1] + d[3] + 3
+        self.deconv5, self.deconv4, self.deconv3, self.deconv2 = deconv(c[5], d[0]), deconv(cat5, d[1]), deconv(cat4, d[2]), deconv(cat3, d[3])
+        self.predict_flow6 = nn.Conv3d(c[5], 3, 3, 1, 1, bias=False)
+        self.predict_flow5, self.predict_flow4 = nn.Conv3d(cat5, 3, 3, 1, 1, bias=False), nn.Conv3d(cat4, 3, 3, 1, 1, bias=False)
+        self.predict_flow3, self.predict_flow2 = nn.Conv3d(cat3, 3, 3, 1, 1, bias=False), nn.Conv3d(cat2, 3, 3, 1, 1, bias=False)
+        for a, b in ((6, 5), (5, 4), (4, 3), (3, 2)):
+            setattr(self, f"upsampled_flow{a}_to_{b}", nn.ConvTranspose3d(3, 3, 4, 2, 1, bias=False))
+
+    def forward(self, x):
+        c2 = self.conv2(self.conv1(x))
+        c3 = self.conv3_1(self.conv3(c2))
+        c4 = self.conv4_1(self.conv4(c3))
+        c5 = self.conv5_1(self.conv5(c4))
+        c6 = self.conv6_1(self.conv6(c5))
+        flow6 = self.predict_flow6(c6)
+        cat5 = torch.cat((c5, self.deconv5(c6), self.upsampled_flow6_to_5(flow6)), 1)
+        flow5 = self.predict_flow5(cat5)
+        cat4 = torch.cat((c4, self.deconv4(cat5), self.upsampled_flow5_to_4(flow5)), 1)
+        flow4 = self.predict_flow4(cat4)
+        cat3 = torch.cat((c3, self.deconv3(cat4), self.upsampled_flow4_to_3(flow4)), 1)
+        flow3 = self.predict_flow3(cat3)
+        cat2 = torch.cat((c2, self.deconv2(cat3), self.upsampled_flow3_to_2(flow3)), 1)
+        flow2 = self.predict_flow2(cat2)
+        flow0 = ops.resize_trilinear(flow2, x.shape[2:], False)
+        return (flow0, flow2, flow3, flow4, flow5, flow6) if self.training else (flow0, flow2)
+
+
+class OpticalFlowReg3d(nn.Module):
+    """models.py:209-292 over volumes: predictor, then every flow scale warps the moving volume."""
+
+    def __init__(self, width_div: int = 1):
+        super().__init__()
+        self.predictor = FlowNetS3D(width_div)
+
+    def forward(self, x):
+        flows = self.predictor(x)
+        return list(flows), [ops.stn3d(f, x[:, 1:2]) for f in flows]
+
+
 def _hash_uniform(idx: torch.Tensor, salt: float) -> torch.Tensor:
     """RNG-free pseudo-random numbers in (-1, 1) from the element index (float64 sin hash)."""
     return 2.0 * torch.frac(torch.sin(idx * 12.9898 + salt * 78.233) * 43758.5453).abs() - 1.0

@@ -13,6 +13,7 @@ conv6's output for other volume sizes.
 from __future__ import annotations
 
 import ctypes
+from dataclasses import dataclass
 from typing import Dict, Tuple
 
 import torch
@@ -24,6 +25,48 @@ from .ops import SLOTS
 
 SPEC = [(2, 16, 7, (2, 2, 1)), (16, 32, 5, (2, 2, 1)), (32, 64, 3, (2, 2, 2)), (64, 128, 3, (2, 2, 2)),
         (128, 256, 3, (2, 2, 2)), (256, 512, 3, (2, 2, 2))]
+
+
+@dataclass
+class Vol:
+    """Channel slice [c0, c0+C) of a channel-last volume buffer (B, D, H, W, ld)."""
+    buf: torch.Tensor
+    dims: Tuple[int, int, int]
+    C: int
+    c0: int = 0
+
+    @property
+    def B(self) -> int:
+        return self.buf.shape[0]
+
+    @property
+    def ld(self) -> int:
+        return self.buf.shape[-1]
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + self.c0 * self.buf.element_size()
+
+    @property
+    def rows(self) -> int:
+        return self.buf.numel() // self.buf.shape[-1]
+
+    @property
+    def bytes_left(self) -> int:
+        return (self.buf.numel() - self.c0) * self.buf.element_size()
+
+    def slice(self, c0: int, C: int) -> "Vol":
+        assert c0 >= 0 and self.c0 + c0 + C <= self.ld
+        return Vol(self.buf, self.dims, C, self.c0 + c0)
+
+    def view2d(self) -> View:
+        """The same rows as an NHWC view (depth folded into H) for the dimension-agnostic row kernels (BatchNorm, masks)."""
+        D, H, W = self.dims
+        return View(self.buf.view(self.B, D * H, W, self.ld), self.B, D * H, W, self.C, self.c0)
+
+
+def _vol(x, dims) -> Vol:
+    return x if isinstance(x, Vol) else Vol(x, tuple(dims), x.shape[-1], 0)
 
 
 class Conv3dLayer:
@@ -48,24 +91,32 @@ class Conv3dLayer:
         return (f(D, self.kd, self.stride[0], self.pad[0]), f(H, self.kh, self.stride[1], self.pad[1]),
                 f(W, self.kw, self.stride[2], self.pad[2]))
 
-    def run(self, x: torch.Tensor, dims: Tuple[int, int, int], y: torch.Tensor, slope: float) -> Tuple[int, int, int]:
-        """x: (B, D, H, W, ld_x) NDHWC buffer, y: (B, Do, Ho, Wo, ld_y)."""
-        B = x.shape[0]
+    def run(self, x, dims: Tuple[int, int, int], y, slope: float, *, y32=None, accumulate: bool = False,
+            bias: bool = True) -> Tuple[int, int, int]:
+        """x: (B, D, H, W, ld_x) channel-last buffer or Vol, y: (B, Do, Ho, Wo, ld_y) buffer or Vol (None with y32 only)."""
+        x = _vol(x, dims)
+        B = x.B
         D, H, W = dims
         Do, Ho, Wo = self.out_dims(D, H, W)
         d = ConvDesc()
-        d.x, d.x_ld, d.x_H, d.x_W, d.x_C, d.x_D = x.data_ptr(), x.shape[-1], H, W, self.Cip, D
+        d.x, d.x_ld, d.x_H, d.x_W, d.x_C, d.x_D = x.ptr, x.ld, H, W, self.Cip, D
         d.taps_z, d.taps_y, d.taps_x = self.kd, self.kh, self.kw
         d.mul_z, d.mul_y, d.mul_x = self.stride
         d.off_z, d.off_y, d.off_x = -self.pad[0], -self.pad[1], -self.pad[2]
         d.step_z = d.step_y = d.step_x = 1
         d.g_D, d.g_H, d.g_W, d.n_img = Do, Ho, Wo, B
         d.w, d.w_ld, d.N = self.packF.data_ptr(), self.Kf, self.Co
-        d.x_bytes, d.w_bytes = x.numel() * x.element_size(), self.packF.numel() * self.packF.element_size()
-        d.y, d.y_ld, d.y_D, d.y_H, d.y_W = y.data_ptr(), y.shape[-1], Do, Ho, Wo
+        d.x_bytes, d.w_bytes = x.bytes_left, self.packF.numel() * self.packF.element_size()
+        if y is not None:
+            y = _vol(y, (Do, Ho, Wo))
+            d.y, d.y_ld = y.ptr, y.ld
+        if y32 is not None:
+            y32 = _vol(y32, (Do, Ho, Wo))
+            d.y32, d.y32_ld = y32.ptr, y32.ld
+        d.y_D, d.y_H, d.y_W = Do, Ho, Wo
         d.y_mul_z = d.y_mul_y = d.y_mul_x = 1
-        d.bias = self.bias.data_ptr() if self.bias is not None else None
-        d.slope, d.dtype, d.split_k = slope, self.ws.code, 1
+        d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
+        d.slope, d.dtype, d.split_k, d.accumulate = slope, self.ws.code, 1, int(accumulate)
         self._launch(d, B * Do * Ho * Wo, self.Co, self.Kf)
         return Do, Ho, Wo
 
@@ -104,9 +155,12 @@ class Conv3dLayer:
                     out.append(dict(par=par, c=c, nt=nt, pack=pk.view(self.Ci, -1)))
         return out
 
-    def dgrad(self, gy: torch.Tensor, odims: Tuple[int, int, int], gx: torch.Tensor, idims: Tuple[int, int, int]) -> None:
-        """gx[(z,y,x), ci] = sum_{taps, co} gy[(z + p - t)/s ..., co] W[co][ci][t]; one GEMM launch per parity class."""
-        B = gy.shape[0]
+    def dgrad(self, gy, odims: Tuple[int, int, int], gx, idims: Tuple[int, int, int], *, slope: float = 1.0,
+              accumulate: bool = False) -> None:
+        """gx[(z,y,x), ci] = act(sum_{taps, co} gy[(z + p - t)/s ..., co] W[co][ci][t]); one GEMM launch per parity class.
+        Also the forward of ConvTranspose3d (whose weight [Cin][Cout][k^3] is this layer's [Co][Ci][k^3])."""
+        gy, gx = _vol(gy, odims), _vol(gx, idims)
+        B = gy.B
         Cop = rup(self.Co, 8)
         self._keep = self.dgrad_classes()
         for k in self._keep:
@@ -114,43 +168,44 @@ class Conv3dLayer:
             if min(g) <= 0:
                 continue
             d = ConvDesc()
-            d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = gy.data_ptr(), gy.shape[-1], odims[0], odims[1], odims[2], Cop
+            d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = gy.ptr, gy.ld, odims[0], odims[1], odims[2], Cop
             d.taps_z, d.taps_y, d.taps_x = k["nt"]
             d.mul_z = d.mul_y = d.mul_x = 1
             d.off_z, d.off_y, d.off_x = k["c"]
             d.step_z = d.step_y = d.step_x = -1
             d.g_D, d.g_H, d.g_W, d.n_img = g[0], g[1], g[2], B
             d.w, d.w_ld, d.N = k["pack"].data_ptr(), k["pack"].shape[1], self.Ci
-            d.x_bytes, d.w_bytes = gy.numel() * gy.element_size(), k["pack"].numel() * k["pack"].element_size()
-            d.y, d.y_ld, d.y_D, d.y_H, d.y_W = gx.data_ptr(), gx.shape[-1], idims[0], idims[1], idims[2]
+            d.x_bytes, d.w_bytes = gy.bytes_left, k["pack"].numel() * k["pack"].element_size()
+            d.y, d.y_ld, d.y_D, d.y_H, d.y_W = gx.ptr, gx.ld, idims[0], idims[1], idims[2]
             d.y_mul_z, d.y_mul_y, d.y_mul_x = self.stride
             d.y_off_z, d.y_off_y, d.y_off_x = k["par"]
-            d.slope, d.dtype = 1.0, self.ws.code
+            d.slope, d.dtype, d.accumulate = slope, self.ws.code, int(accumulate)
             self._launch(d, B * g[0] * g[1] * g[2], self.Ci, k["pack"].shape[1])
 
-    def wgrad(self, x: torch.Tensor, idims: Tuple[int, int, int], gy: torch.Tensor, odims: Tuple[int, int, int]) -> None:
+    def wgrad(self, x, idims: Tuple[int, int, int], gy, odims: Tuple[int, int, int]) -> None:
         """slab[z][co][(tz,ty,tx)*Cip + ci] = sum_voxels gy[v][co] x[v @ tap][ci]: one backward-weights launch per depth tap,
         each filling its column block of the shared slab (mireg_conv_desc.slab_ld)."""
-        B = x.shape[0]
+        x, gy = _vol(x, idims), _vol(gy, odims)
+        B = x.B
         P = B * odims[0] * odims[1] * odims[2]
         K2 = self.kh * self.kw * self.Cip
         tiles = ((self.Co + 127) // 128) * ((K2 + 127) // 128)            # per launch (the depth taps run back to back)
         nk = (P + 31) // 32
         split = 1 if tiles >= 256 else max(1, min(768 // tiles, max(nk // 8, 1), 192))
         if getattr(self, "slab", None) is None or self.slab.shape[0] != split:
-            self.slab = torch.zeros(split, self.Co, self.Kf, device=x.device, dtype=torch.float32)
+            self.slab = torch.zeros(split, self.Co, self.Kf, device=x.buf.device, dtype=torch.float32)
         for tz in range(self.kd):
             d = ConvDesc()
-            d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = x.data_ptr(), x.shape[-1], idims[0], idims[1], idims[2], self.Cip
+            d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, idims[0], idims[1], idims[2], self.Cip
             d.taps_y, d.taps_x = self.kh, self.kw
             d.mul_z, d.mul_y, d.mul_x = self.stride
             d.off_z, d.off_y, d.off_x = tz - self.pad[0], -self.pad[1], -self.pad[2]
             d.step_y = d.step_x = 1
             d.g_D, d.g_H, d.g_W, d.n_img = odims[0], odims[1], odims[2], B
-            d.y, d.y_ld, d.N = gy.data_ptr(), gy.shape[-1], self.Co
+            d.y, d.y_ld, d.N = gy.ptr, gy.ld, self.Co
             d.split_k, d.dtype, d.stages = split, self.ws.code, 3
             d.slab, d.slab_ld = self.slab.data_ptr() + 4 * tz * K2, self.Kf
-            d.x_bytes, d.w_bytes = x.numel() * x.element_size(), gy.numel() * gy.element_size()
+            d.x_bytes, d.w_bytes = x.bytes_left, gy.bytes_left
             _lib.call("mireg_conv_wgrad", ctypes.byref(d), _stream())
 
     def unpack_job(self, grad: torch.Tensor) -> PackJob:
@@ -165,8 +220,8 @@ class Conv3dLayer:
         ws = self.ws
         if ws.colsum_ws is None or ws.colsum_ws.numel() < 64 * max(self.Co, 1024):
             ws.colsum_ws = torch.empty(64 * max(self.Co, 1024), device=ws.device, dtype=torch.float32)
-        M = gy.numel() // gy.shape[-1]
-        _lib.call("mireg_colsum", gy.data_ptr(), gy.shape[-1], M, self.Co, out.data_ptr(), 0, ws.colsum_ws.data_ptr(),
+        gy = _vol(gy, (1, 1, 1))
+        _lib.call("mireg_colsum", gy.ptr, gy.ld, gy.rows, self.Co, out.data_ptr(), 0, ws.colsum_ws.data_ptr(),
                   ws.code, _stream())
 
 

@@ -1,0 +1,265 @@
+"""FlowNetS over volumes -- BASELINE config "3D FlowNetS on 128^3 synthetic brain volumes" (SURVEY section 8 row a14).
+
+The reference has no 3-D FlowNetS; this is its 2-D predictor (FlowNetS/FlowNetS.py:10-91, FlowNetS/util.py:17-55) with every
+Conv2d / BatchNorm2d / ConvTranspose2d replaced by its 3-D counterpart, three flow channels (x, y, z displacement) and the
+same module names, wrapped like reference models.py:209-292 (`opticalFlowReg`): predictor -> per-scale warp of the moving
+volume.  All contractions run on the depth-enabled LDS-DMA implicit-GEMM kernels (forward, backward-data per parity class,
+backward-weights per depth tap), BatchNorm3d + LeakyReLU on the row kernels of the 2-D path, the tail on csrc/volume_ops.hip.
+Training goes through torch.autograd: the predictor is one autograd function whose backward is the HIP backward pass.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .affine3d import Conv3dLayer, Vol
+from .engine import BatchNormAct, Workspace, _stream, assign_tiles, rup, upload_table
+from .volume import resize_trilinear, stn3d
+
+ENC = [("conv1", 7, 2), ("conv2", 5, 2), ("conv3", 5, 2), ("conv3_1", 3, 1), ("conv4", 3, 2), ("conv4_1", 3, 1),
+       ("conv5", 3, 2), ("conv5_1", 3, 1), ("conv6", 3, 2), ("conv6_1", 3, 1)]
+
+
+def _conv(cin: int, cout: int, k: int, s: int) -> nn.Sequential:
+    return nn.Sequential(nn.Conv3d(cin, cout, k, s, (k - 1) // 2, bias=False), nn.BatchNorm3d(cout), nn.LeakyReLU(0.1, inplace=True))
+
+
+def _deconv(cin: int, cout: int) -> nn.Sequential:
+    return nn.Sequential(nn.ConvTranspose3d(cin, cout, 4, 2, 1, bias=False), nn.LeakyReLU(0.1, inplace=True))
+
+
+class _PredictorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        ctx.mod = mod
+        return tuple(mod._forward_impl(x, keep=True))
+
+    @staticmethod
+    def backward(ctx, *gflows):
+        return (None, None, *ctx.mod._backward_impl(gflows))
+
+
+class FlowNetS3D(nn.Module):
+    """FlowNetS (batch-norm variant, the one the reference trains: models.py:252) over volumes.  `width_div` scales every
+    channel width down (tests); volumes must be divisible by 64 per axis (six stride-2 stages, no crop_like needed)."""
+
+    def __init__(self, precision: str = "bf16", width_div: int = 1):
+        super().__init__()
+        self.precision = precision
+        c = [max(8, v // width_div) for v in (64, 128, 256, 512, 512, 1024)]
+        d = [max(8, v // width_div) for v in (512, 256, 128, 64)]                   # deconv5..deconv2 outputs
+        self.c, self.d = c, d
+        cin = [2, c[0], c[1], c[2], c[2], c[3], c[3], c[4], c[4], c[5]]
+        cout = [c[0], c[1], c[2], c[2], c[3], c[3], c[4], c[4], c[5], c[5]]
+        for (name, k, s), ci, co in zip(ENC, cin, cout):
+            setattr(self, name, _conv(ci, co, k, s))
+        self.cat = {5: c[4] + d[0] + 3, 4: c[3] + d[1] + 3, 3: c[2] + d[2] + 3, 2: c[1] + d[3] + 3}
+        self.deconv5 = _deconv(c[5], d[0])
+        self.deconv4 = _deconv(self.cat[5], d[1])
+        self.deconv3 = _deconv(self.cat[4], d[2])
+        self.deconv2 = _deconv(self.cat[3], d[3])
+        self.predict_flow6 = nn.Conv3d(c[5], 3, 3, 1, 1, bias=False)
+        for lv in (5, 4, 3, 2):
+            setattr(self, f"predict_flow{lv}", nn.Conv3d(self.cat[lv], 3, 3, 1, 1, bias=False))
+        for a, b in ((6, 5), (5, 4), (4, 3), (3, 2)):
+            setattr(self, f"upsampled_flow{a}_to_{b}", nn.ConvTranspose3d(3, 3, 4, 2, 1, bias=False))
+        for m in self.modules():                                                     # FlowNetS/FlowNetS.py:45-52
+            if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)):
+                nn.init.kaiming_normal_(m.weight, 0.1)
+            elif isinstance(m, nn.BatchNorm3d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._eng: Dict[tuple, dict] = {}
+        self._last = None
+
+    # ---- engine -----------------------------------------------------------------------------------------------------
+    def _engine(self, x: torch.Tensor) -> dict:
+        dtype = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        key = (tuple(x.shape), x.device, dtype, self.conv1[0].weight.data_ptr())
+        if key in self._eng:
+            return self._eng[key]
+        self._eng.clear()
+        B, C, D, H, W = x.shape
+        if C != 2 or D % 64 or H % 64 or W % 64:
+            raise RuntimeError(f"FlowNetS3D expects (B, 2, D, H, W) volumes divisible by 64 per axis, got {tuple(x.shape)}")
+        dev, ws = x.device, Workspace(x.device, dtype)
+        dims = {0: (D, H, W)}
+        for lv in range(1, 7):
+            dims[lv] = tuple(v // 2 for v in dims[lv - 1])
+        c, d = self.c, self.d
+
+        def buf(lv: int, ch: int, dt=dtype) -> Vol:
+            return Vol(torch.zeros(B, *dims[lv], rup(ch, 8), device=dev, dtype=dt), dims[lv], ch)
+
+        e = dict(ws=ws, dims=dims, x0=buf(0, 2))
+        cat = {lv: buf(lv, self.cat[lv]) for lv in (5, 4, 3, 2)}
+        gcat = {lv: buf(lv, self.cat[lv]) for lv in (5, 4, 3, 2)}
+        # activation (post BatchNorm + LeakyReLU) of every encoder layer, its level, and where its gradient lives
+        lvl = dict(conv1=1, conv2=2, conv3=3, conv3_1=3, conv4=4, conv4_1=4, conv5=5, conv5_1=5, conv6=6, conv6_1=6)
+        skip = dict(conv2=2, conv3_1=3, conv4_1=4, conv5_1=5)                        # layers whose output is a concat slice
+        act, gact, raw, graw, layers, bns = {}, {}, {}, {}, {}, {}
+        for name, k, s in ENC:
+            conv, bn = getattr(self, name)[0], getattr(self, name)[1]
+            co = conv.out_channels
+            if name in skip:
+                act[name], gact[name] = cat[skip[name]].slice(0, co), gcat[skip[name]].slice(0, co)
+            else:
+                act[name], gact[name] = buf(lvl[name], co), buf(lvl[name], co)
+            raw[name], graw[name] = buf(lvl[name], co), buf(lvl[name], co)
+            layers[name] = Conv3dLayer(conv.weight, None, (s, s, s), ((k - 1) // 2,) * 3, ws)
+            bns[name] = BatchNormAct(bn, ws, 0.1)
+        for lv in (6, 5, 4, 3, 2):
+            layers[f"predict_flow{lv}"] = Conv3dLayer(getattr(self, f"predict_flow{lv}").weight, None, (1, 1, 1), (1, 1, 1), ws)
+        for lv in (5, 4, 3, 2):
+            # ConvTranspose3d weight [Cin][Cout][4^3] == Conv3d weight [Co][Ci][4^3] of the adjoint (stride 2, pad 1) convolution
+            layers[f"deconv{lv}"] = Conv3dLayer(getattr(self, f"deconv{lv}")[0].weight, None, (2, 2, 2), (1, 1, 1), ws)
+            layers[f"up{lv}"] = Conv3dLayer(getattr(self, f"upsampled_flow{lv + 1}_to_{lv}").weight, None, (2, 2, 2), (1, 1, 1), ws)
+        e.update(cat=cat, gcat=gcat, act=act, gact=gact, raw=raw, graw=graw, layers=layers, bns=bns,
+                 flow={lv: buf(lv, 3) for lv in (6, 5, 4, 3, 2)}, gflow={lv: buf(lv, 3) for lv in (6, 5, 4, 3, 2)},
+                 flow32={lv: buf(lv, 3, torch.float32) for lv in (6, 5, 4, 3, 2)})
+        self._eng[key] = e
+        return e
+
+    def _named(self) -> List[Tuple[str, nn.Parameter]]:
+        return list(self.named_parameters())
+
+    def forward(self, x: torch.Tensor):
+        """Training: (flow0, flow2, flow3, flow4, flow5, flow6); eval: (flow0, flow2) -- FlowNetS/FlowNetS.py:83-88 with the
+        full-resolution flow0 = trilinear upsample of flow2 (align_corners=False)."""
+        if not x.is_cuda:
+            raise RuntimeError("mireg.FlowNetS3D runs on the MI355X only; there is no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            flows = _PredictorFn.apply(self, x, *[p for _, p in self._named()])
+        else:
+            flows = tuple(self._forward_impl(x, keep=False))
+        flow0 = resize_trilinear(flows[0], tuple(x.shape[2:]), False)
+        return (flow0, *flows) if self.training else (flow0, flows[0])
+
+    def _forward_impl(self, x: torch.Tensor, keep: bool):
+        e = self._engine(x)
+        ws, st, dims, L = e["ws"], _stream(), e["dims"], e["layers"]
+        B, _, D, H, W = x.shape
+        x = x.detach().float().contiguous()
+        jobs = [l.pack_job() for l in L.values()]
+        units, dunits = assign_tiles(jobs, False)
+        tab = upload_table(jobs, x.device)
+        _lib.call("mireg_pack_weights", tab.data_ptr(), len(jobs), units, dunits, ws.code, st)
+        _lib.call("mireg_nchw_to_nhwc", x.data_ptr(), e["x0"].ptr, B, 2, 0, 2, D * H * W, e["x0"].ld, ws.code, st)
+        src, training = e["x0"], self.training
+        for name, k, s in ENC:
+            lay, out = L[name], e["act"][name]
+            lay.run(src, src.dims, e["raw"][name], 1.0)
+            e["bns"][name].forward(e["raw"][name].view2d(), out.view2d(), training)
+            src = out
+        c, d, cat = self.c, self.d, e["cat"]
+        feat = e["act"]["conv6_1"]
+        for lv in (6, 5, 4, 3, 2):
+            L[f"predict_flow{lv}"].run(feat, dims[lv], e["flow"][lv], 1.0, y32=e["flow32"][lv])
+            if lv == 2:
+                break
+            nxt, dm = cat[lv - 1], d[6 - lv]                                         # deconv{lv-1} has d[5 - (lv-1)] outputs
+            skipc = nxt.C - 3 - dm                                                   # channels of the encoder skip in the next concat
+            # deconv (LeakyReLU 0.1) and the flow upsampler are backward-data-form launches into their concat slices
+            L[f"deconv{lv - 1}"].dgrad(feat, dims[lv], nxt.slice(skipc, dm), dims[lv - 1], slope=0.1)
+            L[f"up{lv - 1}"].dgrad(e["flow"][lv], dims[lv], nxt.slice(skipc + dm, 3), dims[lv - 1])
+            feat = nxt
+        self._last = dict(e=e, B=B) if keep else None
+        # logical (B, 3, d, h, w) views of the channel-last fp32 flows (valid until the next forward of this module)
+        return [e["flow32"][lv].buf[..., :3].permute(0, 4, 1, 2, 3) for lv in (2, 3, 4, 5, 6)]
+
+    def _backward_impl(self, gflows):
+        if self._last is None:
+            raise RuntimeError("FlowNetS3D backward without a saved forward (one forward in flight per module)")
+        e, B = self._last["e"], self._last["B"]
+        self._last = None
+        ws, st, dims, L, d = e["ws"], _stream(), e["dims"], e["layers"], self.d
+        cat, gcat, act, gact = e["cat"], e["gcat"], e["act"], e["gact"]
+        dev = e["x0"].buf.device
+        for g, lv in zip(gflows, (2, 3, 4, 5, 6)):
+            gf = e["gflow"][lv]
+            if g is None:
+                gf.buf.zero_()
+                continue
+            g = g.float().contiguous()
+            nv = dims[lv][0] * dims[lv][1] * dims[lv][2]
+            _lib.call("mireg_nchw_to_nhwc", g.data_ptr(), gf.ptr, B, 3, 0, 3, nv, gf.ld, ws.code, st)
+
+        def mask(g: Vol, a: Vol, slope: float) -> None:
+            _lib.call("mireg_lrelu_bwd", g.ptr, g.ld, a.ptr, a.ld, g.rows, g.C, slope, ws.code, st)
+
+        # ---- decoder, fine to coarse ----
+        for lv in (2, 3, 4, 5, 6):
+            feat = cat[lv] if lv < 6 else act["conv6_1"]
+            gfeat = gcat[lv] if lv < 6 else gact["conv6_1"]
+            pf = L[f"predict_flow{lv}"]
+            pf.wgrad(feat, dims[lv], e["gflow"][lv], dims[lv])
+            pf.dgrad(e["gflow"][lv], dims[lv], gfeat, dims[lv], accumulate=(lv > 2))   # level 2 opens gcat2, deeper levels add
+            if lv == 6:
+                break
+            dm = d[5 - lv]                                                           # outputs of deconv{lv}
+            skipc = feat.C - 3 - dm
+            gup, gdec = gfeat.slice(skipc + dm, 3), gfeat.slice(skipc, dm)
+            up, dec = L[f"up{lv}"], L[f"deconv{lv}"]
+            below = cat[lv + 1] if lv + 1 < 6 else act["conv6_1"]
+            gbelow = gcat[lv + 1] if lv + 1 < 6 else gact["conv6_1"]
+            # flow upsampler (ConvTranspose3d 3 -> 3): d/d flow_{lv+1} adds to its loss gradient; weight gradient
+            up.run(gup, dims[lv], e["gflow"][lv + 1], 1.0, accumulate=True)
+            up.wgrad(gup, dims[lv], e["flow"][lv + 1], dims[lv + 1])
+            # deconv: LeakyReLU mask, then backward-data (conv form of the adjoint) opens the gradient of the level below
+            mask(gdec, feat.slice(skipc, dm), 0.1)
+            dec.run(gdec, dims[lv], gbelow, 1.0)
+            dec.wgrad(gdec, dims[lv], below, dims[lv + 1])
+        # ---- encoder, deep to shallow ----
+        prev = {n: (ENC[i - 1][0] if i else None) for i, (n, _, _) in enumerate(ENC)}
+        for name, k, s in reversed(ENC):
+            lay, bn = L[name], e["bns"][name]
+            bn.backward(e["raw"][name].view2d(), gact[name].view2d(), e["graw"][name].view2d())
+            src = act[prev[name]] if prev[name] else e["x0"]
+            odims = e["raw"][name].dims
+            lay.wgrad(src, src.dims, e["graw"][name], odims)
+            if prev[name]:
+                # skip tensors already hold the decoder's contribution (they are concat slices): accumulate there
+                lay.dgrad(e["graw"][name], odims, gact[prev[name]], src.dims, accumulate=prev[name] in ("conv2", "conv3_1", "conv4_1", "conv5_1"))
+        # ---- gradients in named_parameters() order ----
+        grads, jobs = [], []
+        conv_of = {}
+        for name, _, _ in ENC:
+            conv_of[f"{name}.0.weight"] = L[name]
+        for lv in (6, 5, 4, 3, 2):
+            conv_of[f"predict_flow{lv}.weight"] = L[f"predict_flow{lv}"]
+        for lv in (5, 4, 3, 2):
+            conv_of[f"deconv{lv}.0.weight"] = L[f"deconv{lv}"]
+            conv_of[f"upsampled_flow{lv + 1}_to_{lv}.weight"] = L[f"up{lv}"]
+        for pname, p in self._named():
+            if pname in conv_of:
+                g = torch.zeros_like(p, dtype=torch.float32)
+                jobs.append(conv_of[pname].unpack_job(g))
+            else:                                                                    # BatchNorm3d weight / bias
+                lname, _, kind = pname.split(".")
+                g = (e["bns"][lname].grad_g if kind == "weight" else e["bns"][lname].grad_b).clone()
+            grads.append(g)
+        units, _ = assign_tiles(jobs, True)
+        tab = upload_table(jobs, dev)
+        _lib.call("mireg_unpack_wgrad", tab.data_ptr(), len(jobs), units, st)
+        e["_tab"] = tab
+        return [g.to(p.dtype) for g, (_, p) in zip(grads, self._named())]
+
+
+class opticalFlowReg3d(nn.Module):
+    """reference models.opticalFlowReg (models.py:209-292) over volumes: `(x) -> (flows, warped)` with x = (B, 2, D, H, W) =
+    [fixed, moving]; every flow scale warps the moving volume (`stn3d`).  Segmentations ride the same warp:
+    `stn3d(flows[0], seg)` then mireg.seg_round / mireg.dice_average as in 2-D."""
+
+    def __init__(self, precision: str = "bf16", width_div: int = 1):
+        super().__init__()
+        self.predictor = FlowNetS3D(precision, width_div)
+
+    stn = staticmethod(stn3d)
+
+    def forward(self, x: torch.Tensor):
+        flows = self.predictor(x)
+        moving = x[:, 1:2]
+        return list(flows), [stn3d(f, moving) for f in flows]
