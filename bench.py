@@ -236,28 +236,68 @@ def main():
     # affine grid / trilinear sampling + Affloss on synthetic 128^3 pairs, B = 8 (BASELINE configs[4] batch) ----------------
     vol_line = None
     if rank == 0 and not args.no_3d:
+        def timed(fn, n, warm=2):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                out = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n, out
+
         try:
             g = torch.Generator(device="cpu").manual_seed(6)
             low = torch.rand(8, 2, 8, 8, 8, generator=g)
             vol = torch.nn.functional.interpolate(low, size=(128, 128, 128), mode="trilinear", align_corners=False).to(dev)
             aff = mireg.affmodel(fc_in=512 * 2 * 2 * 8, precision=args.precision).to(dev).eval()
-            with torch.no_grad():
-                for _ in range(2):
+
+            def aff_eval():
+                with torch.no_grad():
                     para, wv = aff(vol)
-                    mireg.Affloss(wv, vol[:, 0:1])
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                n3 = 5
-                for _ in range(n3):
-                    para, wv = aff(vol)
-                    l3 = mireg.Affloss(wv, vol[:, 0:1])
-                torch.cuda.synchronize()
-            t3 = (time.perf_counter() - t0) / n3
+                    return mireg.Affloss(wv, vol[:, 0:1])
+            t3, l3 = timed(aff_eval, 5)
             vol_line = {"volumes_per_s": round(8 / t3, 1), "ms_per_batch": round(t3 * 1e3, 3), "batch": 8, "size": "128x128x128",
                         "loss": float(l3[2]), "note": "affmodel forward (6 Conv3d+ReLU on the depth-enabled GEMM, Linear, fused affine-grid "
-                        "trilinear sampler) + Affloss, eager, 1 GPU; forward / evaluation only (no 3-D backward kernels yet)"}
+                        "trilinear sampler) + Affloss, eager, 1 GPU"}
+            log(f"3-D affmodel eval: {8 / t3:.1f} volumes/s")
+            aff.train()
+            opt_a = mireg.Adam(aff.parameters(), 1e-4, eps=1e-4)
+
+            def aff_train():
+                para, wv = aff(vol)
+                loss = mireg.Affloss(wv, vol[:, 0:1])[2]
+                opt_a.zero_grad()
+                loss.backward()
+                opt_a.step()
+                return loss
+            t3, l3 = timed(aff_train, 5)
+            vol_line["affmodel_train"] = {"volumes_per_s": round(8 / t3, 1), "ms_per_step": round(t3 * 1e3, 3), "loss": float(l3.detach()),
+                                          "note": "forward + Affloss + HIP backward (Conv3d backward-data / backward-weights, sampler "
+                                                  "d/d theta) + Adam, eager"}
+            log(f"3-D affmodel train: {8 / t3:.1f} volumes/s")
+            del aff, opt_a
+            torch.cuda.empty_cache()
+            # BASELINE configs[4]: FlowNetS over 128^3 volumes, batch 8 -- full widths, train step
+            reg3 = mireg.opticalFlowReg3d(precision=args.precision).to(dev).train()
+            opt_f = mireg.Adam(reg3.parameters(), 1e-4, eps=1e-4)
+
+            def f3_train():
+                flows, warped = reg3(vol)
+                loss = mireg.OFEloss3d(flows, warped, vol[:, 0:1])[3]
+                opt_f.zero_grad()
+                loss.backward()
+                opt_f.step()
+                return loss
+            t3, l3 = timed(f3_train, 3, warm=1)
+            vol_line["flownets3d_train"] = {"volumes_per_s": round(8 / t3, 1), "ms_per_step": round(t3 * 1e3, 3), "loss": float(l3.detach()),
+                                            "batch": 8, "note": "configs[4]: FlowNetS over 128^3 volume pairs (Conv3d / BatchNorm3d / "
+                                            "ConvTranspose3d, 3-channel flow), six-scale warp + OFEloss3d, HIP backward, Adam; eager, 1 GPU"}
+            log(f"3-D FlowNetS train: {8 / t3:.2f} volumes/s ({t3 * 1e3:.1f} ms/step)")
+            del reg3, opt_f
+            torch.cuda.empty_cache()
         except Exception as e:
-            vol_line = {"error": repr(e)}
+            vol_line = dict(vol_line or {}, error=repr(e))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

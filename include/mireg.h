@@ -216,6 +216,18 @@ int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int total_unit
                        hipStream_t stream);
 int mireg_unpack_wgrad(const mireg_pack_job* jobs_dev, int njobs, int total_units, hipStream_t stream);
 
+/* Conv3d backward-data packs (all parity classes of a layer from one pass over its torch-layout weight [Co][Ci][kd][kh][kw]):
+ * class (cz,cy,cx), index (cz*sy + cy)*sx + cx, holds the taps t_a with (c_a + pad_a) % s_a == t_a % s_a as its tap
+ * j_a = t_a / s_a:  dst[class][ci][(jz*nty + jy)*ntx + jx][Cop] = W[co][ci][tz][ty][tx], pad output channels zeroed.
+ * units = Ci * ceil(Cop/64) per job.  ConvTranspose3d weights [Cin][Cout][k^3] are the Conv3d weights of the adjoint. */
+typedef struct mireg_pack3d_job {
+  const float* src; void* dst[8];
+  int Co, Ci, Cop;
+  int kd, kh, kw, sz, sy, sx, pz, py, px;   /* kernel extent, stride, padding per axis (z, y, x) */
+  int unit0;
+} mireg_pack3d_job;
+int mireg_pack_dgrad3d(const mireg_pack3d_job* jobs_dev, int njobs, int total_units, int dtype, hipStream_t stream);
+
 /* ---- two-output-channel 3x3 / stride 1 / pad 1 convolutions (predict_flow heads: FlowNetS/util.py:33-34,
  * flownet2/networks/submodules.py:32-33, PWC/models/PWCNet.py:31-32) on the vector ALUs.  w = the FWD pack
  * [2][9*Cpad] of mireg_pack_weights; x / dx = wide NHWC tensors (Cpad channels walked, 16-byte aligned rows);

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import DT_BF16, DT_F32, ConvDesc, PackJob, View, Workspace, _stream, assign_tiles, rup, upload_table
+from .engine import DT_BF16, DT_F32, ConvDesc, Pack3dJob, PackJob, View, Workspace, _stream, assign_tiles, rup, upload_table
 from .ops import SLOTS
 
 SPEC = [(2, 16, 7, (2, 2, 1)), (16, 32, 5, (2, 2, 1)), (32, 64, 3, (2, 2, 2)), (64, 128, 3, (2, 2, 2)),
@@ -136,24 +136,50 @@ class Conv3dLayer:
     # ---- backward (autograd of nn.Conv3d, reference models.py:39-43 trained through loss.backward()) ----
     def dgrad_classes(self) -> list:
         """Per output-voxel parity class (pz, py, px) of the backward-data form: the taps t = r + s*j that reach it, packed
-        [Ci][(jz, jy, jx)][Cop] (host-side slicing of the fp32 weight; a few small tensors per step)."""
-        W = self.weight.detach().float()
-        Cop = rup(self.Co, 8)
-        out = []
-        for pz in range(self.stride[0]):
-            for py in range(self.stride[1]):
-                for px in range(self.stride[2]):
-                    par = (pz, py, px)
-                    r = [(par[a] + self.pad[a]) % self.stride[a] for a in range(3)]
-                    c = [(par[a] + self.pad[a]) // self.stride[a] for a in range(3)]
-                    sub = W[:, :, r[0]::self.stride[0], r[1]::self.stride[1], r[2]::self.stride[2]]
-                    nt = tuple(sub.shape[2:])
-                    if min(nt) == 0:
-                        raise ValueError("Conv3d kernel smaller than its stride is not supported")
-                    pk = torch.zeros(self.Ci, nt[0] * nt[1] * nt[2], Cop, device=W.device, dtype=self.ws.dtype)
-                    pk[:, :, :self.Co] = sub.permute(1, 2, 3, 4, 0).reshape(self.Ci, -1, self.Co)
-                    out.append(dict(par=par, c=c, nt=nt, pack=pk.view(self.Ci, -1)))
-        return out
+        [Ci][(jz, jy, jx)][Cop] by mireg_pack_dgrad3d (persistent buffers; class order = the kernel's (cz*sy + cy)*sx + cx)."""
+        if getattr(self, "_cls", None) is None:
+            Cop = rup(self.Co, 8)
+            self._cls = []
+            for pz in range(self.stride[0]):
+                for py in range(self.stride[1]):
+                    for px in range(self.stride[2]):
+                        par = (pz, py, px)
+                        r = [(par[a] + self.pad[a]) % self.stride[a] for a in range(3)]
+                        c = [(par[a] + self.pad[a]) // self.stride[a] for a in range(3)]
+                        k = (self.kd, self.kh, self.kw)
+                        nt = tuple(max(0, (k[a] - r[a] + self.stride[a] - 1) // self.stride[a]) for a in range(3))
+                        if min(nt) == 0:
+                            raise ValueError("Conv3d kernel smaller than its stride is not supported")
+                        pk = torch.zeros(self.Ci, nt[0] * nt[1] * nt[2] * Cop, device=self.ws.device, dtype=self.ws.dtype)
+                        self._cls.append(dict(par=par, c=c, nt=nt, pack=pk))
+        return self._cls
+
+    def pack3d_job(self) -> Pack3dJob:
+        cls = self.dgrad_classes()
+        j = Pack3dJob()
+        j.src = self.weight.data_ptr()
+        for i, k in enumerate(cls):
+            j.dst[i] = k["pack"].data_ptr()
+        j.Co, j.Ci, j.Cop = self.Co, self.Ci, rup(self.Co, 8)
+        j.kd, j.kh, j.kw = self.kd, self.kh, self.kw
+        j.sz, j.sy, j.sx = self.stride
+        j.pz, j.py, j.px = self.pad
+        return j
+
+    @staticmethod
+    def pack_dgrad_table(layers, ws: Workspace) -> torch.Tensor:
+        """One launch for the backward-data packs of `layers`; marks them fresh (dgrad() repacks a stale layer on its own)."""
+        jobs, u = [], 0
+        for l in layers:
+            j = l.pack3d_job()
+            j.unit0 = u
+            u += l.Ci * ((rup(l.Co, 8) + 63) // 64)
+            jobs.append(j)
+        tab = upload_table(jobs, ws.device)
+        _lib.call("mireg_pack_dgrad3d", tab.data_ptr(), len(jobs), u, ws.code, _stream())
+        for l in layers:
+            l.dfresh = True
+        return tab
 
     def dgrad(self, gy, odims: Tuple[int, int, int], gx, idims: Tuple[int, int, int], *, slope: float = 1.0,
               accumulate: bool = False) -> None:
@@ -162,8 +188,12 @@ class Conv3dLayer:
         gy, gx = _vol(gy, odims), _vol(gx, idims)
         B = gy.B
         Cop = rup(self.Co, 8)
-        self._keep = self.dgrad_classes()
-        for k in self._keep:
+        if self.weight.dtype != torch.float32 or not self.weight.is_contiguous():
+            raise RuntimeError("Conv3dLayer expects contiguous float32 weights")
+        if not getattr(self, "dfresh", False):
+            self._tab3 = self.pack_dgrad_table([self], self.ws)
+        self.dfresh = False                                   # the packs serve one backward-data pass; weights may move after it
+        for k in self.dgrad_classes():
             g = [(idims[a] - k["par"][a] + self.stride[a] - 1) // self.stride[a] for a in range(3)]
             if min(g) <= 0:
                 continue
@@ -344,6 +374,7 @@ class affmodel(nn.Module):
         params = self._params()
         grads = [torch.zeros_like(p, dtype=torch.float32) for p in params]
         one = (1, 1, 1)
+        e["_tab3"] = Conv3dLayer.pack_dgrad_table([fc] + layers[1:], ws)     # backward-data packs of this step's weights
         fc.wgrad(bufs[5], dl[6], gp, one)
         fc.bias_grad(gp, grads[13])
         fc.dgrad(gp, one, e["g"][5], dl[6])

@@ -88,23 +88,43 @@ __global__ void __launch_bounds__(256) pack_fwd_kernel(const mireg_pack_job* __r
     const int nci = max(0, min(64, j.Ci - ci0));        // real channels in this chunk
     const int run = nci * taps;
     const unsigned magic = (unsigned)((0x100000000ull + taps - 1) / taps);
-    if (taps > kPackMaxTaps) {                           // rare (7x7 stem with 1-2 input channels): direct gather
-      if (MODE == 0) {
-        for (int e = lane; e < 64 * taps; e += 64) {
-          const int tap = e / 64, ci = e - tap * 64;
-          if (ci0 + ci < j.Cpad)
-            stf(reinterpret_cast<T*>(j.dst) + (long)co * j.ld + (long)tap * j.Cpad + ci0 + ci,
-                ci < nci ? ldf(j.src + ((long)co * j.Ci + ci0 + ci) * taps + tap) : 0.f);
-        }
-      } else {
-        for (int r = lane; r < run; r += 64) {            // r = ci*taps + tap: every lane busy, z-loads pipelined
-          const int ci = (int)__umulhi((unsigned)r, magic), tap = r - ci * taps;
-          const float* sp = j.src + (long)co * j.ld + (long)tap * j.Cpad + ci0 + ci;
-          float v = 0.f;
-#pragma unroll 8
-          for (int z = 0; z < j.nsplit; ++z) v += ldf(sp + (long)z * j.Co * j.ld);
-          float* d = reinterpret_cast<float*>(j.dst) + ((long)co * j.Ci + ci0) * taps + r;
-          stf(d, j.accumulate ? ldf(d) + v : v);
+    if (taps > kPackMaxTaps) {                           // 7x7 stems and every Conv3d (27..343 taps): same tile, tap chunks
+      for (int t0 = 0; t0 < taps; t0 += kPackMaxTaps) {
+        const int nt = min(kPackMaxTaps, taps - t0), ntp = nt | 1;
+        const unsigned mg = (unsigned)((0x100000000ull + nt - 1) / nt);
+        __builtin_amdgcn_wave_barrier();
+        if (MODE == 0) {
+          const float* src = j.src + ((long)co * j.Ci + ci0) * taps + t0;
+          for (int r = lane; r < nci * nt; r += 64) {     // runs of nt contiguous floats per input channel
+            const int ci = (int)__umulhi((unsigned)r, mg);
+            tile[ci * ntp + (r - ci * nt)] = ldf(src + (long)ci * taps + (r - ci * nt));
+          }
+          __builtin_amdgcn_wave_barrier();
+          T* dst = reinterpret_cast<T*>(j.dst) + (long)co * j.ld + (long)t0 * j.Cpad + ci0 + lane;
+          if (ci0 + lane < j.Cpad) {
+#pragma unroll 4
+            for (int t = 0; t < nt; ++t) stf(dst + (long)t * j.Cpad, lane < nci ? tile[lane * ntp + t] : 0.f);
+          }
+        } else {
+          if (lane < nci) {
+            const float* sp = j.src + (long)co * j.ld + (long)t0 * j.Cpad + ci0 + lane;
+            const long slab_sz = (long)j.Co * j.ld;
+#pragma unroll 4
+            for (int t = 0; t < nt; ++t) {
+              float v = 0.f;
+#pragma unroll 4
+              for (int z = 0; z < j.nsplit; ++z) v += ldf(sp + (long)t * j.Cpad + z * slab_sz);
+              tile[lane * ntp + t] = v;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          float* d = reinterpret_cast<float*>(j.dst) + ((long)co * j.Ci + ci0) * taps + t0;
+          for (int r = lane; r < nci * nt; r += 64) {
+            const int ci = (int)__umulhi((unsigned)r, mg), t = r - ci * nt;
+            const float v = tile[ci * ntp + t];
+            float* q = d + (long)ci * taps + t;
+            stf(q, j.accumulate ? ldf(q) + v : v);
+          }
         }
       }
       continue;
@@ -139,6 +159,41 @@ __global__ void __launch_bounds__(256) pack_fwd_kernel(const mireg_pack_job* __r
         const int ci = (int)__umulhi((unsigned)r, magic);
         const float v = tile[ci * tp + (r - ci * taps)];
         stf(d + r, j.accumulate ? ldf(d + r) + v : v);
+      }
+    }
+  }
+}
+
+// Conv3d backward-data packs, all output-voxel parity classes of a layer in one pass over its weights:
+// tap t_a of axis a reaches the voxels of parity p_a with (p_a + pad_a) % s_a == t_a % s_a, as that class's tap j_a = t_a / s_a;
+// D_class[ci][(jz, jy, jx)][Cop] = W[co][ci][tz][ty][tx].  Unit = (ci, 64 output channels): lanes walk co, so every store is a
+// contiguous run; each lane reads its own taps-long run of the torch-layout weight (served from L2 after the first tap).
+template <typename T>
+__global__ void __launch_bounds__(256) pack_dgrad3d_kernel(const mireg_pack3d_job* __restrict__ jobs, int njobs, int total_units) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int unit = blockIdx.x * 4 + wid; unit < total_units; unit += gridDim.x * 4) {
+    int ji = 0;
+    for (int i = 1; i < njobs; ++i) if (jobs[i].unit0 <= unit) ji = i;
+    const mireg_pack3d_job* __restrict__ jp = jobs + ji;        // fields are read through the table pointer (no private copy)
+    const int Co = jp->Co, Ci = jp->Ci, Cop = jp->Cop, kd = jp->kd, kh = jp->kh, kw = jp->kw;
+    const int sz = jp->sz, sy = jp->sy, sx = jp->sx, pz = jp->pz, py = jp->py, px = jp->px;
+    const int chunks = (Cop + 63) / 64, u = unit - jp->unit0;
+    const int ci = u / chunks, co = (u - ci * chunks) * 64 + lane;
+    if (co >= Cop) continue;
+    const int taps = kd * kh * kw;
+    const float* src = jp->src + ((long)co * Ci + ci) * taps;
+    const bool real = co < Co;
+    for (int tz = 0; tz < kd; ++tz) {
+      const int rz = tz % sz, cz = ((rz - pz) % sz + sz) % sz, ntz = (kd - rz + sz - 1) / sz;
+      for (int ty = 0; ty < kh; ++ty) {
+        const int ry = ty % sy, cy = ((ry - py) % sy + sy) % sy, nty = (kh - ry + sy - 1) / sy;
+        for (int tx = 0; tx < kw; ++tx) {
+          const int rx = tx % sx, cx = ((rx - px) % sx + sx) % sx, ntx = (kw - rx + sx - 1) / sx;
+          const int cls = (cz * sy + cy) * sx + cx;
+          const long jidx = ((long)(tz / sz) * nty + ty / sy) * ntx + tx / sx;
+          T* dst = reinterpret_cast<T*>(jp->dst[cls]) + ((long)ci * (ntz * nty * ntx) + jidx) * Cop + co;
+          stf(dst, real ? ldf(src + (tz * kh + ty) * kw + tx) : 0.f);
+        }
       }
     }
   }
@@ -758,6 +813,15 @@ int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int total_unit
     if (total_units) hipLaunchKernelGGL((pack_fwd_kernel<float, 0>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
     if (total_dgrad_units) hipLaunchKernelGGL((pack_dgrad_kernel<float>), dim3(total_dgrad_units), dim3(256), 0, stream, jobs_dev, njobs);
   }
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_pack_dgrad3d(const mireg_pack3d_job* jobs_dev, int njobs, int total_units, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units > 0);
+  MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
+  const int g = total_units / 4 + 1 < 8192 ? total_units / 4 + 1 : 8192;
+  if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((pack_dgrad3d_kernel<__bf16>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
+  else hipLaunchKernelGGL((pack_dgrad3d_kernel<float>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
   MIREG_LAUNCH_RET();
 }
 

@@ -94,6 +94,13 @@ def zero_many_table(bufs: Sequence[torch.Tensor], device):
     return upload_table(jobs, device), len(jobs), u
 
 
+class Pack3dJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p * 8), ("Co", ctypes.c_int), ("Ci", ctypes.c_int),
+                ("Cop", ctypes.c_int), ("kd", ctypes.c_int), ("kh", ctypes.c_int), ("kw", ctypes.c_int),
+                ("sz", ctypes.c_int), ("sy", ctypes.c_int), ("sx", ctypes.c_int), ("pz", ctypes.c_int), ("py", ctypes.c_int),
+                ("px", ctypes.c_int), ("unit0", ctypes.c_int)]
+
+
 class AdamJob(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
                 ("n", ctypes.c_long)]

@@ -147,6 +147,9 @@ class FlowNetS3D(nn.Module):
         units, dunits = assign_tiles(jobs, False)
         tab = upload_table(jobs, x.device)
         _lib.call("mireg_pack_weights", tab.data_ptr(), len(jobs), units, dunits, ws.code, st)
+        # backward-data packs: the deconvolutions / flow upsamplers run that form forward, every other layer (bar conv1) backward
+        need = [l for n, l in L.items() if n != "conv1" and (keep or n.startswith(("deconv", "up")))]
+        e["_tab3"] = Conv3dLayer.pack_dgrad_table(need, ws)
         _lib.call("mireg_nchw_to_nhwc", x.data_ptr(), e["x0"].ptr, B, 2, 0, 2, D * H * W, e["x0"].ld, ws.code, st)
         src, training = e["x0"], self.training
         for name, k, s in ENC:

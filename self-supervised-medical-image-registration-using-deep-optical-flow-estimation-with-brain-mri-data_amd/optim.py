@@ -1,0 +1,61 @@
+"""torch.optim.Adam on the HIP multi-tensor kernel (`mireg_adam_step`), for the models that train through torch.autograd
+(the volume path).  Same update as torch.optim.Adam without weight decay / amsgrad; the reference builds its optimizer as
+Adam(lr, betas=(0.9, 0.999), eps=1e-4) (train.py:129).  The 2-D trainer has its own packed-domain optimizer.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Tuple
+
+import torch
+
+from . import _lib
+from .engine import AdamJob, _stream, upload_table
+
+
+class Adam:
+    CHUNK = 1 << 18
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-8):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        for p in self.params:
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("mireg.Adam updates contiguous float32 parameters on the MI355X only; there is no CPU fallback")
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.offs, n = [], 0
+        for p in self.params:                                  # 16-byte aligned moment slices keep the kernel on its float4 path
+            self.offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        dev = self.params[0].device
+        self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self._tab = None
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    def step(self) -> None:
+        jobs, keep = [], []
+        for p, off in zip(self.params, self.offs):
+            n = p.numel()
+            if p.grad is not None:
+                g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
+                keep.append(g)
+                # the kernel gives every table entry the same few workgroups: cut large tensors into CHUNK-element entries
+                for c0 in range(0, n, self.CHUNK):
+                    o = 4 * c0
+                    jobs.append(AdamJob(p.data_ptr() + o, g.data_ptr() + o, self.m.data_ptr() + 4 * off + o,
+                                        self.v.data_ptr() + 4 * off + o, min(self.CHUNK, n - c0)))
+        if not jobs:
+            return
+        self._tab, self._keep = upload_table(jobs, self.params[0].device), keep       # alive until the launch has run
+        _lib.call("mireg_adam_step", self._tab.data_ptr(), len(jobs), self.step_dev.data_ptr(), 1, self.lr, self.betas[0],
+                  self.betas[1], self.eps, 1.0, _stream())

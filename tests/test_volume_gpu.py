@@ -167,3 +167,19 @@ def test_flownets3d_adam_steps_reduce_loss():
         opt.step()
         losses.append(loss.item())
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+def test_mireg_adam_matches_torch_adam():
+    import mireg
+    torch.manual_seed(1)
+    ps = [torch.randn(s, device=DEV).requires_grad_(True) for s in ((7, 3, 3, 3, 3), (5,), (12, 33), (3, 1 << 18, 1))]
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    a, b = mireg.Adam(ps, 1e-3, eps=1e-4), torch.optim.Adam(qs, 1e-3, eps=1e-4)
+    for it in range(5):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        a.step()
+        b.step()
+    for p, q in zip(ps, qs):
+        assert (p - q).abs().max().item() < 1e-6
