@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import DT_BF16, DT_F32, ConvDesc, Pack3dJob, PackJob, View, Workspace, _stream, assign_tiles, rup, upload_table
+from .engine import DT_BF16, DT_F32, ConvDesc, Pack3dJob, PackJob, View, WoptJob, Workspace, _stream, assign_tiles, rup, upload_table
 from .ops import SLOTS
 
 SPEC = [(2, 16, 7, (2, 2, 1)), (16, 32, 5, (2, 2, 1)), (32, 64, 3, (2, 2, 2)), (64, 128, 3, (2, 2, 2)),
@@ -238,12 +238,36 @@ class Conv3dLayer:
             d.x_bytes, d.w_bytes = x.bytes_left, gy.bytes_left
             _lib.call("mireg_conv_wgrad", ctypes.byref(d), _stream())
 
-    def unpack_job(self, grad: torch.Tensor) -> PackJob:
+    @staticmethod
+    def unpack_grads(pairs, ws: Workspace):
+        """pairs = [(layer, torch-layout fp32 gradient)]: sum the split-K slabs in place (fully parallel, fixed order), then one
+        transposing pass slab[co][(tap, ci)] -> grad[co][ci][tap].  Returns the device tables (keep them until the stream ran)."""
+        st, red, r = _stream(), [], 0
+        for lay, _ in pairs:
+            if lay.slab.shape[0] > 1:
+                j = WoptJob()
+                j.slab = j.g = lay.slab.data_ptr()
+                j.slab_stride, j.nsplit = lay.Co * lay.Kf, lay.slab.shape[0]
+                j.Co, j.Ci, j.taps, j.Cpad, j.ld = lay.Co, lay.Ci, lay.kd * lay.kh * lay.kw, lay.Cip, lay.Kf
+                j.runit0 = r
+                r += (lay.Co * lay.Kf + 255) // 256
+                red.append(j)
+        tabs = []
+        if red:
+            tabs.append(upload_table(red, ws.device))
+            _lib.call("mireg_wgrad_reduce", tabs[-1].data_ptr(), len(red), r, st)
+        jobs = [lay.unpack_job(g, 1) for lay, g in pairs]
+        units, _ = assign_tiles(jobs, True)
+        tabs.append(upload_table(jobs, ws.device))
+        _lib.call("mireg_unpack_wgrad", tabs[-1].data_ptr(), len(jobs), units, st)
+        return tabs
+
+    def unpack_job(self, grad: torch.Tensor, nsplit: int = 0) -> PackJob:
         j = PackJob()
         j.src, j.dst = self.slab.data_ptr(), grad.data_ptr()
         j.Co, j.Ci, j.kh, j.kw = self.Co, self.Ci, self.kd * self.kh, self.kw
         j.Cpad, j.Cop, j.ld, j.stride, j.nclass = self.Cip, rup(self.Co, 8), self.Kf, 1, 0
-        j.nsplit, j.accumulate = self.slab.shape[0], 0
+        j.nsplit, j.accumulate = (nsplit or self.slab.shape[0]), 0
         return j
 
     def bias_grad(self, gy: torch.Tensor, out: torch.Tensor) -> None:
@@ -387,11 +411,7 @@ class affmodel(nn.Module):
             lay.bias_grad(g, grads[2 * i + 1])
             if i > 0:
                 lay.dgrad(g, dl[i + 1], e["g"][i - 1], dl[i])
-        jobs = [layers[i].unpack_job(grads[2 * i]) for i in range(6)] + [fc.unpack_job(grads[12])]
-        units, _ = assign_tiles(jobs, True)
-        tab = upload_table(jobs, dev)
-        _lib.call("mireg_unpack_wgrad", tab.data_ptr(), len(jobs), units, st)
-        e["_tab"] = tab
+        e["_tab"] = Conv3dLayer.unpack_grads([(layers[i], grads[2 * i]) for i in range(6)] + [(fc, grads[12])], ws)
         return [g.to(p.dtype) for g, p in zip(grads, params)]
 
 

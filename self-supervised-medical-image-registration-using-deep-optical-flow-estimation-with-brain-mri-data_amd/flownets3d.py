@@ -227,7 +227,7 @@ class FlowNetS3D(nn.Module):
                 # skip tensors already hold the decoder's contribution (they are concat slices): accumulate there
                 lay.dgrad(e["graw"][name], odims, gact[prev[name]], src.dims, accumulate=prev[name] in ("conv2", "conv3_1", "conv4_1", "conv5_1"))
         # ---- gradients in named_parameters() order ----
-        grads, jobs = [], []
+        grads, pairs = [], []
         conv_of = {}
         for name, _, _ in ENC:
             conv_of[f"{name}.0.weight"] = L[name]
@@ -238,16 +238,13 @@ class FlowNetS3D(nn.Module):
             conv_of[f"upsampled_flow{lv + 1}_to_{lv}.weight"] = L[f"up{lv}"]
         for pname, p in self._named():
             if pname in conv_of:
-                g = torch.zeros_like(p, dtype=torch.float32)
-                jobs.append(conv_of[pname].unpack_job(g))
+                g = torch.empty_like(p, dtype=torch.float32)          # every element is written by the unpack
+                pairs.append((conv_of[pname], g))
             else:                                                                    # BatchNorm3d weight / bias
                 lname, _, kind = pname.split(".")
                 g = (e["bns"][lname].grad_g if kind == "weight" else e["bns"][lname].grad_b).clone()
             grads.append(g)
-        units, _ = assign_tiles(jobs, True)
-        tab = upload_table(jobs, dev)
-        _lib.call("mireg_unpack_wgrad", tab.data_ptr(), len(jobs), units, st)
-        e["_tab"] = tab
+        e["_tab"] = Conv3dLayer.unpack_grads(pairs, ws)
         return [g.to(p.dtype) for g, (_, p) in zip(grads, self._named())]
 
 
