@@ -186,6 +186,23 @@ def main():
                                     "GBps": round(v["flops"] / (v["ms"] * 1e-3) / 1e9, 1),
                                     "frac_of_8TBps": round(v["flops"] / (v["ms"] * 1e-3) / 8e12, 4)} for k, v in hbm.items()}}
 
+        # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process, so the figure is
+        # the committed `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum` pass over this same command (eager launches,
+        # scratch/pmc_bench.sh), per launch, with the guide's gfx950 correction: wide (16 B/lane) reads are tallied at half
+        # their bytes -> 2 * RDREQ * 64 B + WRREQ * 64 B.  null when the summary is absent or the kernel differs.
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_conv_kernels.json")))
+            if dom[0].startswith("conv_wgrad") and args.model == "flownets" and args.batch == 24 and args.size == 256:
+                ent = next(v for k, v in pmc.items() if "conv_wgrad_dma_kernel" in k)
+                rd, wr = ent["TCC_EA0_RDREQ_sum"]["mean_per_launch"], ent["TCC_EA0_WRREQ_sum"]["mean_per_launch"]
+                roof["traffic"] = round(2 * rd * 64 + wr * 64)
+                roof["traffic_note"] = ("bytes per launch, mean over the backward-weights launches of the step, from "
+                                        "profiles/round1_pmc_conv_kernels.json (separate rocprofv3 --pmc pass); algorithmic "
+                                        "bytes per launch (x + dy once, dW once): 23.4 MB -> operand re-reads across output "
+                                        "tiles and split-K slab writes dominate")
+        except Exception as e:                                       # noqa: BLE001 -- the bench line must still print
+            roof["traffic_note"] = f"PMC summary unavailable: {e!r}"
+
     # ---- quality leg: warped Dice of the (random-init, K-step-trained) model, GPU vs CPU oracle ---------------
     dice = None
     if rank == 0:

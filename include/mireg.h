@@ -127,6 +127,12 @@ int mireg_smoothness3d_fwd(const float* flow, long fsb, long fsc, long fsp, doub
                            hipStream_t stream);
 int mireg_smoothness3d_bwd(const float* flow, long fsb, long fsc, long fsp, const float* coef, float* gflow, float beta, int B,
                            int d, int h, int w, hipStream_t stream);
+/* x-axis im2col of a few-channel planar fp32 volume (the 7^3 / stride-2 / 2-channel input convolution of FlowNetS over
+ * volumes, the 3-D counterpart of FlowNetS/FlowNetS.py:18): dst[b][z][y][xo][tx*C + c] = x[b][c][z][y][xo*stride + tx - pad]
+ * (zeros outside and in the pad channels), dst channel-last with Cpad >= k*C channels (a multiple of 8), Wo = (W + 2*pad - k)/stride + 1.
+ * The convolution then runs as a (k, k, 1) / stride (s, s, 1) Conv3d over k*C -> Cpad channels on mireg_conv_gemm. */
+int mireg_stem3d_gather(const float* x, void* dst, int B, int C, int D, int H, int W, int k, int stride, int pad, int Cpad,
+                        int dtype, hipStream_t stream);
 
 /* ---- K14/K15: models.py:286 (rint + clip 0..3, on device), utils.py:72-91 (Dice) --------- */
 int mireg_seg_round(const float* in, float* out, long n, hipStream_t stream);

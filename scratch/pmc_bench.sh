@@ -1,18 +1,23 @@
 #!/bin/bash
 # usage: scratch/pmc_bench.sh <tag> "<counters>" <kernel substring>
+# PMC pass over the default bench workload (eager launches, launch shapes from a tuning pass done outside the profile)
 TAG=$1; CNT=$2; PAT=$3
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$TAG
-rocprofv3 --pmc $CNT --output-format csv -d $R/gpurun_out/$TAG/pmc -- python3 $R/bench.py --steps 1 --warmup 3 --no-cpu-baseline --no-graph --no-autotune > $R/gpurun_out/$TAG/out.txt 2> $R/gpurun_out/$TAG/err.txt
+timeout -k 10 200 python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-3d --tune-cache $R/gpurun_out/$TAG/tune.json > /dev/null 2>&1
+timeout -k 10 400 rocprofv3 --pmc $CNT --output-format csv -d $R/gpurun_out/$TAG/pmc -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-3d --no-graph --tune-cache $R/gpurun_out/$TAG/tune.json > $R/gpurun_out/$TAG/out.txt 2> $R/gpurun_out/$TAG/err.txt
 F=$(find $R/gpurun_out/$TAG/pmc -name "*counter_collection.csv" | head -1)
-python3 - "$F" "$PAT" <<'PY'
-import csv, sys, collections
+python3 - "$F" "$PAT" $R/gpurun_out/$TAG/summary.json <<'PY'
+import csv, sys, collections, json
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    agg[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
 for k, d in agg.items():
     if sys.argv[2] not in k: continue
+    out[k] = {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in d.items()}
     print(k, {c: round(sum(v)/len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
+json.dump(out, open(sys.argv[3], "w"), indent=1)
 PY

@@ -221,7 +221,7 @@ class Conv3dLayer:
         K2 = self.kh * self.kw * self.Cip
         tiles = ((self.Co + 127) // 128) * ((K2 + 127) // 128)            # per launch (the depth taps run back to back)
         nk = (P + 31) // 32
-        split = 1 if tiles >= 256 else max(1, min(768 // tiles, max(nk // 8, 1), 192))
+        split = 1 if tiles >= 256 else max(1, min(768 // tiles, max(nk // 8, 1)))      # up to three workgroups per CU resident
         if getattr(self, "slab", None) is None or self.slab.shape[0] != split:
             self.slab = torch.zeros(split, self.Co, self.Kf, device=x.buf.device, dtype=torch.float32)
         for tz in range(self.kd):

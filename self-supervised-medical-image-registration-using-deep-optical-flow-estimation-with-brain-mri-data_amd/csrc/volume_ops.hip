@@ -241,6 +241,43 @@ smooth3d_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp
   }
 }
 
+
+// ---- x-axis im2col of a few-channel volume (the stem of FlowNetS over volumes) ---------------------------------------------
+// dst[b][z][y][xo][tx*C + c] = x[b][c][z][y][xo*stride + tx - pad] (zero outside, pad channels zero): a k^3 / C-channel
+// convolution becomes a (k, k, 1) convolution over k*C -> Cpad channels, so the GEMM's 8-channel K granules carry
+// k*C/Cpad real data instead of C/8 (2 of 8 for the two-channel input: 4x less gathered bytes and MFMA work).
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+stem3d_gather_kernel(const float* __restrict__ x, T* __restrict__ dst, int B, int C, int D, int H, int W, int Wo, int k, int stride,
+                     int pad, int Cpad) {
+  // one thread per (voxel, 8-channel granule): consecutive threads write consecutive 16/32-byte granules
+  const int gpv = Cpad / 8;
+  const long total = (long)B * D * H * Wo * gpv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % gpv);
+    long r = i / gpv;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int y = (int)(r % H); r /= H;
+    const int z = (int)(r % D);
+    const int b = (int)(r / D);
+    const float* row = x + (((long)b * C * D + z) * H + y) * W;          // channel c adds c * D*H*W
+    T v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cp = g * 8 + e;
+      float f = 0.f;
+      if (cp < k * C) {
+        const int tx = cp / C, c = cp - tx * C, xi = xo * stride + tx - pad;
+        if (xi >= 0 && xi < W) f = row[(long)c * D * H * W + xi];
+      }
+      v[e] = (T)f;
+    }
+    T* d = dst + i * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = v[e];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -292,6 +329,23 @@ int mireg_smoothness3d_bwd(const float* flow, long fsb, long fsc, long fsp, cons
   MIREG_CHECK_ARG(flow && coef && gflow && B > 0 && d > 0 && h > 0 && w > 0);
   hipLaunchKernelGGL(smooth3d_bwd_kernel, dim3(grid_for((long)B * d * h * w)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, coef,
                      gflow, beta, B, d, h, w);
+  MIREG_LAUNCH_RET();
+}
+
+
+int mireg_stem3d_gather(const float* x, void* dst, int B, int C, int D, int H, int W, int k, int stride, int pad, int Cpad,
+                        int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(x && dst && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && k > 0 && stride > 0 && pad >= 0 && Cpad >= k * C && Cpad % 8 == 0);
+  MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
+  const int Wo = (W + 2 * pad - k) / stride + 1;
+  MIREG_CHECK_ARG(Wo > 0);
+  const long total = (long)B * D * H * Wo * (Cpad / 8);
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((stem3d_gather_kernel<__bf16>), dim3(grid_for(total, 16384)), dim3(kThreads), 0, stream, x,
+                       reinterpret_cast<__bf16*>(dst), B, C, D, H, W, Wo, k, stride, pad, Cpad);
+  else
+    hipLaunchKernelGGL((stem3d_gather_kernel<float>), dim3(grid_for(total, 16384)), dim3(kThreads), 0, stream, x,
+                       reinterpret_cast<float*>(dst), B, C, D, H, W, Wo, k, stride, pad, Cpad);
   MIREG_LAUNCH_RET();
 }
 
