@@ -187,12 +187,18 @@ __global__ void __launch_bounds__(256) pack_dgrad3d_kernel(const mireg_pack3d_jo
       const int rz = tz % sz, cz = ((rz - pz) % sz + sz) % sz, ntz = (kd - rz + sz - 1) / sz;
       for (int ty = 0; ty < kh; ++ty) {
         const int ry = ty % sy, cy = ((ry - py) % sy + sy) % sy, nty = (kh - ry + sy - 1) / sy;
-        for (int tx = 0; tx < kw; ++tx) {
+        // the kw (<= 8) loads of a tap row are issued together, then stored (one load in flight per wave is latency-bound)
+        float v[8];
+#pragma unroll
+        for (int tx = 0; tx < 8; ++tx) v[tx] = (real && tx < kw) ? ldf(src + (tz * kh + ty) * kw + tx) : 0.f;
+#pragma unroll
+        for (int tx = 0; tx < 8; ++tx) {
+          if (tx >= kw) break;
           const int rx = tx % sx, cx = ((rx - px) % sx + sx) % sx, ntx = (kw - rx + sx - 1) / sx;
           const int cls = (cz * sy + cy) * sx + cx;
           const long jidx = ((long)(tz / sz) * nty + ty / sy) * ntx + tx / sx;
           T* dst = reinterpret_cast<T*>(jp->dst[cls]) + ((long)ci * (ntz * nty * ntx) + jidx) * Cop + co;
-          stf(dst, real ? ldf(src + (tz * kh + ty) * kw + tx) : 0.f);
+          stf(dst, v[tx]);
         }
       }
     }
@@ -817,7 +823,7 @@ int mireg_pack_weights(const mireg_pack_job* jobs_dev, int njobs, int total_unit
 }
 
 int mireg_pack_dgrad3d(const mireg_pack3d_job* jobs_dev, int njobs, int total_units, int dtype, hipStream_t stream) {
-  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units > 0);
+  MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units > 0);       // kernel extents up to 8 per axis
   MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
   const int g = total_units / 4 + 1 < 8192 ? total_units / 4 + 1 : 8192;
   if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((pack_dgrad3d_kernel<__bf16>), dim3(g), dim3(256), 0, stream, jobs_dev, njobs, total_units);
