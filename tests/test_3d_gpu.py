@@ -171,3 +171,22 @@ def test_affmodel_adam_steps_reduce_loss():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0], losses
+
+
+def test_affmodel_reference_volume_size_trains():
+    """The reference's hard-wired shape (models.py:167: fc = Linear(176 * 512, 12) <=> 256 x 256 x 176 volumes), batch 1:
+    forward + Affloss + backward run, the sampler output matches the oracle's sampler on the predicted parameters."""
+    import mireg
+    x = nets.analytic_input((1, 2, 256, 256, 176), seed=21).to(DEV)
+    m = mireg.affmodel(precision="bf16").to(DEV).train()
+    with torch.no_grad():
+        m.fc.weight.mul_(0.01)
+        m.fc.bias.copy_(torch.eye(3, 4).flatten() + 0.02)
+    para, warped = m(x)
+    assert para.shape == (1, 3, 4) and warped.shape == (1, 1, 256, 256, 176)
+    loss = mireg.Affloss(warped, x[:, 0:1])[2]
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max().item() > 0, k
+    ref = oops.affine_grid_sample_3d(x[:, 1:2].cpu(), para.detach().cpu())
+    assert (warped.detach().cpu() - ref).abs().max().item() < 1e-4

@@ -183,3 +183,22 @@ def test_mireg_adam_matches_torch_adam():
         b.step()
     for p, q in zip(ps, qs):
         assert (p - q).abs().max().item() < 1e-6
+
+
+def test_flownets3d_non_cubic_volume_eval():
+    """Per-axis sizes differ (64 x 128 x 64): every level keeps its own (d, h, w); eval mode uses the running statistics."""
+    import mireg
+    x = nets.analytic_input((1, 2, 64, 128, 64), seed=14)
+    o = _ref3d(8, x, train=False)
+    with torch.no_grad():
+        flows_ref, warped_ref = o(x)
+    m = mireg.opticalFlowReg3d(precision="fp32", width_div=8)
+    m.load_state_dict(o.state_dict())
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        flows, warped = m(x.to(DEV))
+    assert flows[0].shape == (1, 3, 64, 128, 64) and flows[1].shape == (1, 3, 16, 32, 16)
+    for a, b in zip(flows, flows_ref):
+        assert (a.cpu() - b).abs().max().item() < 1e-3 * max(1.0, b.abs().max().item())
+    with pytest.raises(RuntimeError, match="divisible by 64"):
+        m(torch.zeros(1, 2, 64, 96, 64, device=DEV))
