@@ -246,6 +246,18 @@ def main():
             t_ev = (time.perf_counter() - t0) / n_ev
             ev_line = {"pairs_per_s": round(args.batch / t_ev, 1), "ms_per_batch": round(t_ev * 1e3, 3),
                        "note": "inference.py:43-68 shaped: eval forward + stn + OFEloss + seg warp/round + per-sample Dice, 1 GPU, eager"}
+            # the same batch with the per-sample metric block of inference.py:69-75 (MSE, PSNR, Pearson, mutual information)
+            evm = trainer.evaluate(xs, ss, metrics=True)
+            if "mse" in evm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_ev):
+                    evm = trainer.evaluate(xs, ss, metrics=True)
+                torch.cuda.synchronize()
+                t_m = (time.perf_counter() - t0) / n_ev
+                ev_line["with_metrics"] = {"pairs_per_s": round(args.batch / t_m, 1), "ms_per_batch": round(t_m * 1e3, 3),
+                                           "mean_mse": float(evm["mse"].mean()), "mean_psnr": float(evm["psnr"].mean()),
+                                           "mean_corr": float(evm["corr"].mean()), "mean_mi": float(evm["mi"].mean())}
         except Exception as e:
             ev_line = {"error": repr(e)}
 

@@ -141,6 +141,17 @@ int mireg_dice(const float* y_true, const float* y_pred, float* counts, float* d
                hipStream_t stream);
 
 
+/* ---- per-sample evaluation metrics of the inference loop (inference.py:66-75) ----
+ * fixed / warped: B samples of n contiguous floats.  mireg_pair_metrics: out[b] = {MSE (utils.py:41-42), PSNR (utils.py:45-49:
+ * 100 when mse < 1e-10), Pearson correlation (utils.py:58-59)} as float64; sums = workspace of B*8 doubles.
+ * mireg_mutual_info: utils.py:52-55, sklearn.metrics.mutual_info_score (natural log) of the labels round(x * scale) clipped to
+ * [0, bins); joint = B*bins*bins ints, marg = B*2*bins ints: workspaces that must be ZERO on entry and are zero again on
+ * exit (only the touched counters are cleared, there is no dense memset or scan); out[b] float64.
+ * The reference uses scale 1500 on [0,1] images: bins = 1501. */
+int mireg_pair_metrics(const float* fixed, const float* warped, double* sums, double* out, int B, long n, hipStream_t stream);
+int mireg_mutual_info(const float* fixed, const float* warped, int* joint, int* marg, double* out, int B, long n, int bins,
+                      float scale, hipStream_t stream);
+
 /* ---- K1-K4: implicit-GEMM convolution family on MFMA ------------------------------------- */
 /* One descriptor drives three contractions (all NHWC, pixel stride `ld` in elements, so producers
  * write straight into channel slices of concat buffers -- replaces torch.cat, FlowNetS.py:64-79):

@@ -339,6 +339,46 @@ def pwc_warp(x: torch.Tensor, flo: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------
+# per-sample evaluation metrics (utils.py:41-59)
+# ----------------------------------------------------------------------------
+def mse(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
+    """utils.py:41-42."""
+    return torch.mean(torch.pow(warped - fixed, 2))
+
+
+def psnr(fixed: torch.Tensor, warped: torch.Tensor):
+    """utils.py:45-49."""
+    m = mse(fixed, warped)
+    if m < 1.0e-10:
+        return torch.tensor(100.0)
+    return 10 * torch.log10(1.0 ** 2 / m)
+
+
+def pearson(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
+    """utils.py:58-59 CORR = torchmetrics.functional.pearson_corrcoef (dependency absent here, version unpinned): the
+    published definition cov / (sigma_x sigma_y), in float64."""
+    x, y = fixed.reshape(-1).double(), warped.reshape(-1).double()
+    vx, vy = x - x.mean(), y - y.mean()
+    return (vx * vy).sum() / torch.sqrt((vx * vx).sum() * (vy * vy).sum())
+
+
+def mutual_info(fixed: torch.Tensor, warped: torch.Tensor, scale: float = 1500.0) -> float:
+    """utils.py:52-55: sklearn.metrics.mutual_info_score(round(fixed*1500), round(warped*1500)); restated from its published
+    definition sum_ij n_ij/N * log(N n_ij / (a_i b_j)) (natural log); tests also call sklearn's own function when importable."""
+    a = torch.round(fixed * scale).int().reshape(-1).numpy()
+    b = torch.round(warped * scale).int().reshape(-1).numpy()
+    n = a.size
+    _, ai = np.unique(a, return_inverse=True)
+    _, bi = np.unique(b, return_inverse=True)
+    cont = np.zeros((ai.max() + 1, bi.max() + 1), dtype=np.int64)
+    np.add.at(cont, (ai, bi), 1)
+    ra, cb = cont.sum(1), cont.sum(0)
+    i, j = np.nonzero(cont)
+    nij = cont[i, j].astype(np.float64)
+    return float(np.sum(nij / n * (np.log(nij) + np.log(n) - np.log(ra[i]) - np.log(cb[j]))))
+
+
+# ----------------------------------------------------------------------------
 # a14: 3-D affine grid + trilinear sampling (models.py:187-188)
 # ----------------------------------------------------------------------------
 def affine_grid_sample_3d(vol: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:

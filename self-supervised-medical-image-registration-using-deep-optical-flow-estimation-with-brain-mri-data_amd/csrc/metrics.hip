@@ -1,0 +1,165 @@
+// metrics.hip -- per-sample evaluation metrics of the inference loop on device (reference inference.py:66-75 calls them once
+// per sample and pulls every result to the host):
+//   MSE  utils.py:41-42    mean((warped - fixed)^2)
+//   PSNR utils.py:45-49    100 if mse < 1e-10 else 10*log10(1/mse)
+//   CORR utils.py:58-59    Pearson correlation of the flattened images (torchmetrics.pearson_corrcoef)
+//   MI   utils.py:52-55    sklearn.metrics.mutual_info_score of round(x*1500) labels (natural log)
+// One launch covers the whole batch for the moment-based three; MI counts into a dense joint table per sample (bins^2 int32),
+// sums log(N n_ij / (a_i b_j)) over the PIXELS (not the cells) and zeroes the touched counters again: three launches per batch.
+#include "mireg_common.h"
+#include "../../include/mireg.h"
+
+using namespace mireg;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// sums[b][8] = {S a, S b, S ab, S aa, S bb, S (a-b)^2, -, -}; a = fixed, b = warped
+__global__ void __launch_bounds__(kThreads)
+pair_moments_kernel(const float* __restrict__ fixed, const float* __restrict__ warped, double* __restrict__ sums, long n) {
+  __shared__ float red[6 * (kThreads / 64)];
+  const int b = blockIdx.y;
+  const float* f = fixed + (long)b * n;
+  const float* w = warped + (long)b * n;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = f[i], y = w[i], d = y - x;
+    acc[0] += x; acc[1] += y; acc[2] += x * y; acc[3] += x * x; acc[4] += y * y; acc[5] += d * d;
+  }
+  block_sum<6>(acc, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) atomicAdd(&sums[b * 8 + k], (double)acc[k]);
+  }
+}
+
+// out[b][3] = {mse, psnr, pearson}
+__global__ void pair_metrics_finalize_kernel(const double* __restrict__ sums, double* __restrict__ out, int B, long n) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* s = sums + b * 8;
+  const double N = (double)n;
+  const double mse = s[5] / N;
+  const double cov = s[2] - s[0] * s[1] / N, va = s[3] - s[0] * s[0] / N, vb = s[4] - s[1] * s[1] / N;
+  out[b * 3 + 0] = mse;
+  out[b * 3 + 1] = mse < 1.0e-10 ? 100.0 : 10.0 * log10(1.0 / mse);
+  out[b * 3 + 2] = cov / sqrt(va * vb);                  // 0/0 -> NaN for a constant image, as the reference's dependency gives
+}
+
+__device__ __forceinline__ int label_of(float v, float scale, int bins) {
+  const int q = (int)rintf(v * scale);                   // torch.round = round-half-even
+  return min(max(q, 0), bins - 1);
+}
+
+// counter += 1 per lane, with the lanes of a wave that hit the same counter combined first: smooth images put thousands of
+// pixels (the background above all) into one cell, and one-by-one atomics on a single address serialise in L2.  Two leader
+// rounds catch the dominant keys; whatever is left goes one atomic per lane.
+__device__ __forceinline__ void count_key(int* __restrict__ table, int key, bool active) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(active);
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if (!todo) break;
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lk = __shfl(key, leader, 64);
+    const unsigned long long same = __ballot(active && key == lk) & todo;
+    if (lane == leader) atomicAdd(&table[lk], (int)__popcll(same));
+    todo &= ~same;
+  }
+  if ((todo >> lane) & 1ull) atomicAdd(&table[key], 1);
+}
+
+// pass 1: joint[b][a*bins + c] and the two marginals of every sample (blockIdx.y = sample)
+__global__ void __launch_bounds__(kThreads)
+mi_count_kernel(const float* __restrict__ fixed, const float* __restrict__ warped, int* __restrict__ joint, int* __restrict__ marg,
+                long n, int bins, float scale) {
+  const int s = blockIdx.y;
+  const float* f = fixed + (long)s * n;
+  const float* w = warped + (long)s * n;
+  int* jt = joint + (long)s * bins * bins;
+  int* mg = marg + (long)s * 2 * bins;
+  const long span = (long)gridDim.x * blockDim.x, trips = (n + span - 1) / span;      // uniform trip count: ballots need every lane
+  for (long t = 0; t < trips; ++t) {
+    const long i = t * span + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < n;
+    const int a = ok ? label_of(f[i], scale, bins) : 0, c = ok ? label_of(w[i], scale, bins) : 0;
+    count_key(jt, a * bins + c, ok);
+    count_key(mg, a, ok);
+    count_key(mg, bins + c, ok);
+  }
+}
+
+// pass 2: MI = sum_ij (n_ij/N) log(N n_ij / (a_i b_j)) = (1/N) sum over PIXELS of log(N n_ij / (a_i b_j)) at the pixel's cell
+// (sklearn.metrics.mutual_info_score, natural log) -- no scan of the dense table
+__global__ void __launch_bounds__(kThreads)
+mi_sum_kernel(const float* __restrict__ fixed, const float* __restrict__ warped, const int* __restrict__ joint,
+              const int* __restrict__ marg, double* __restrict__ out, long n, int bins, float scale) {
+  __shared__ double red[kThreads / 64];
+  const int s = blockIdx.y;
+  const float* f = fixed + (long)s * n;
+  const float* w = warped + (long)s * n;
+  const int* jt = joint + (long)s * bins * bins;
+  const int* mg = marg + (long)s * 2 * bins;
+  const double logN = log((double)n);
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int a = label_of(f[i], scale, bins), c = label_of(w[i], scale, bins);
+    acc += log((double)jt[(long)a * bins + c]) + logN - log((double)mg[a]) - log((double)mg[bins + c]);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kThreads / 64; ++k) t += red[k];
+    atomicAdd(out + s, t / (double)n);
+  }
+}
+
+// pass 3: put the touched counters back to zero (the tables stay clean between calls; no dense memset)
+__global__ void __launch_bounds__(kThreads)
+mi_clear_kernel(const float* __restrict__ fixed, const float* __restrict__ warped, int* __restrict__ joint, int* __restrict__ marg,
+                long n, int bins, float scale) {
+  const int s = blockIdx.y;
+  const float* f = fixed + (long)s * n;
+  const float* w = warped + (long)s * n;
+  int* jt = joint + (long)s * bins * bins;
+  int* mg = marg + (long)s * 2 * bins;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int a = label_of(f[i], scale, bins), c = label_of(w[i], scale, bins);
+    jt[(long)a * bins + c] = 0;
+    mg[a] = 0;
+    mg[bins + c] = 0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mireg_pair_metrics(const float* fixed, const float* warped, double* sums, double* out, int B, long n, hipStream_t stream) {
+  MIREG_CHECK_ARG(fixed && warped && sums && out && B > 0 && n > 0);
+  if (hipMemsetAsync(sums, 0, (size_t)B * 8 * sizeof(double), stream) != hipSuccess) return MIREG_ERR_LAUNCH;
+  long g = (n + kThreads * 4 - 1) / (kThreads * 4);
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(pair_moments_kernel, dim3((unsigned)g, B), dim3(kThreads), 0, stream, fixed, warped, sums, n);
+  hipLaunchKernelGGL(pair_metrics_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, sums, out, B, n);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_mutual_info(const float* fixed, const float* warped, int* joint, int* marg, double* out, int B, long n, int bins,
+                      float scale, hipStream_t stream) {
+  MIREG_CHECK_ARG(fixed && warped && joint && marg && out && B > 0 && n > 0 && bins > 1 && bins <= 8192);
+  if (hipMemsetAsync(out, 0, (size_t)B * sizeof(double), stream) != hipSuccess) return MIREG_ERR_LAUNCH;
+  long g = (n + kThreads - 1) / kThreads;
+  if (g > 256) g = 256;
+  const dim3 grid((unsigned)g, B);
+  hipLaunchKernelGGL(mi_count_kernel, grid, dim3(kThreads), 0, stream, fixed, warped, joint, marg, n, bins, scale);
+  hipLaunchKernelGGL(mi_sum_kernel, grid, dim3(kThreads), 0, stream, fixed, warped, joint, marg, out, n, bins, scale);
+  hipLaunchKernelGGL(mi_clear_kernel, grid, dim3(kThreads), 0, stream, fixed, warped, joint, marg, n, bins, scale);
+  MIREG_LAUNCH_RET();
+}
+
+}  // extern "C"

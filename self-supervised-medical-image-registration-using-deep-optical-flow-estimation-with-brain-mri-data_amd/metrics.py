@@ -1,0 +1,71 @@
+"""Per-sample evaluation metrics of the reference's inference loop on device (inference.py:66-75, utils.py:41-59): the
+reference computes each of them sample by sample and pulls every scalar to the host; here one call covers the batch and the
+results stay on the device.  Same names and argument order as reference utils.py (fixed, warped); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import _lib
+from .ops import _need_gpu, _stream
+
+MI_SCALE, MI_BINS = 1500.0, 1501          # utils.py:53-54: round(x * 1500) on [0, 1] images
+_MI_WS: dict = {}
+
+
+def _as_batch(fixed: torch.Tensor, warped: torch.Tensor):
+    _need_gpu(fixed, warped)
+    if fixed.shape != warped.shape:
+        raise RuntimeError(f"metrics: fixed {tuple(fixed.shape)} and warped {tuple(warped.shape)} differ")
+    return fixed.contiguous(), warped.contiguous()
+
+
+def pair_metrics(fixed: torch.Tensor, warped: torch.Tensor, mutual_info: bool = True) -> Dict[str, torch.Tensor]:
+    """fixed / warped: (B, ...) batches -> {"mse", "psnr", "corr"[, "mi"]}: float64 tensors of shape (B,), one value per sample
+    (what inference.py:66-75 feeds its running averages with)."""
+    f, w = _as_batch(fixed, warped)
+    B = f.shape[0]
+    n = f.numel() // B
+    dev, st = f.device, _stream()
+    sums = torch.empty(B, 8, device=dev, dtype=torch.float64)
+    out = torch.empty(B, 3, device=dev, dtype=torch.float64)
+    _lib.call("mireg_pair_metrics", f.data_ptr(), w.data_ptr(), sums.data_ptr(), out.data_ptr(), B, n, st)
+    res = {"mse": out[:, 0], "psnr": out[:, 1], "corr": out[:, 2]}
+    if mutual_info:
+        key = (dev, B)
+        if key not in _MI_WS:                                  # zeroed once; the kernels leave the tables clean
+            _MI_WS.clear()
+            _MI_WS[key] = (torch.zeros(B * MI_BINS * MI_BINS, device=dev, dtype=torch.int32),
+                           torch.zeros(B * 2 * MI_BINS, device=dev, dtype=torch.int32))
+        joint, marg = _MI_WS[key]
+        mi = torch.empty(B, device=dev, dtype=torch.float64)
+        _lib.call("mireg_mutual_info", f.data_ptr(), w.data_ptr(), joint.data_ptr(), marg.data_ptr(), mi.data_ptr(), B, n, MI_BINS,
+                  MI_SCALE, st)
+        res["mi"] = mi
+    return res
+
+
+def _single(fixed: torch.Tensor, warped: torch.Tensor, key: str) -> torch.Tensor:
+    return pair_metrics(fixed.unsqueeze(0), warped.unsqueeze(0), mutual_info=(key == "mi"))[key][0]
+
+
+def MSE(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference utils.MSE (utils.py:41-42) on one sample."""
+    return _single(fixed, warped, "mse")
+
+
+def PSNR(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference utils.PSNR (utils.py:45-49)."""
+    return _single(fixed, warped, "psnr")
+
+
+def CORR(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference utils.CORR (utils.py:58-59)."""
+    return _single(fixed, warped, "corr")
+
+
+def MI(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference utils.MI (utils.py:52-55)."""
+    return _single(fixed, warped, "mi")

@@ -473,8 +473,9 @@ class RegistrationTrainer:
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def evaluate(self, x: torch.Tensor, segs: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """Eval forward + OFEloss (+ warped-segmentation Dice per sample), reference inference.py:43-68."""
+    def evaluate(self, x: torch.Tensor, segs: Optional[torch.Tensor] = None, metrics: bool = False) -> Dict[str, torch.Tensor]:
+        """Eval forward + OFEloss (+ warped-segmentation Dice per sample), reference inference.py:43-68; metrics=True adds the
+        per-sample MSE / PSNR / Pearson / mutual information of inference.py:69-75 (utils.py:41-59), all left on the device."""
         from . import ops
         self.model.eval()
         flows, warped, wseg, _ = self.model(x, segs)
@@ -483,6 +484,9 @@ class RegistrationTrainer:
         if segs is not None and tuple(wseg.shape[2:]) == tuple(segs.shape[2:]):
             # predictors whose finest flow is not at image resolution (FlowNetC: 64x64) have no Dice in the reference either
             out["dice"] = ops.dice_batch(segs[:, 0:1].float().contiguous(), wseg)
+        if metrics and tuple(warped[0].shape) == tuple(x[:, 0:1].shape):
+            from .metrics import pair_metrics
+            out.update(pair_metrics(x[:, 0:1].contiguous(), warped[0]))
         self.model.train()
         return out
 

@@ -1,0 +1,46 @@
+"""GPU parity of the per-sample evaluation metrics (reference utils.py:41-59, called per sample at inference.py:66-75)."""
+import pytest
+import torch
+
+from oracle import nets, ops as oops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pair(B, size, seed):
+    f = nets.analytic_input((B, 1, size, size), seed=seed)
+    w = (0.8 * f + 0.2 * nets.analytic_input((B, 1, size, size), seed=seed + 1)).clamp(0, 1)
+    return f, w
+
+
+def test_pair_metrics_batch_vs_oracle():
+    import mireg
+    f, w = _pair(5, 256, 3)
+    res = mireg.pair_metrics(f.to(DEV), w.to(DEV))
+    for b in range(5):
+        fb, wb = f[b, 0], w[b, 0]
+        assert abs(res["mse"][b].item() - oops.mse(fb, wb).item()) < 1e-6 * max(1.0, oops.mse(fb, wb).item()) + 1e-9
+        assert abs(res["psnr"][b].item() - float(oops.psnr(fb, wb))) < 1e-4
+        assert abs(res["corr"][b].item() - oops.pearson(fb, wb).item()) < 1e-6
+        assert abs(res["mi"][b].item() - oops.mutual_info(fb, wb)) < 1e-9 * 1e3
+    sk = pytest.importorskip("sklearn.metrics")
+    a = torch.round(f[0, 0] * 1500).int().reshape(-1).numpy()
+    b = torch.round(w[0, 0] * 1500).int().reshape(-1).numpy()
+    assert abs(res["mi"][0].item() - sk.mutual_info_score(a, b)) < 1e-6        # the reference's own dependency
+
+
+def test_reference_named_single_sample_calls_and_edge_cases():
+    import mireg
+    f, w = _pair(1, 64, 7)
+    fd, wd = f[0, 0].to(DEV), w[0, 0].to(DEV)
+    assert abs(mireg.MSE(fd, wd).item() - oops.mse(f[0, 0], w[0, 0]).item()) < 1e-8
+    assert abs(mireg.PSNR(fd, wd).item() - float(oops.psnr(f[0, 0], w[0, 0]))) < 1e-4
+    assert abs(mireg.CORR(fd, wd).item() - oops.pearson(f[0, 0], w[0, 0]).item()) < 1e-6
+    assert abs(mireg.MI(fd, wd).item() - oops.mutual_info(f[0, 0], w[0, 0])) < 1e-6
+    assert mireg.PSNR(fd, fd).item() == 100.0                                  # utils.py:47-48: identical images
+    assert abs(mireg.MI(fd, fd).item() - oops.mutual_info(f[0, 0], f[0, 0])) < 1e-6   # entropy of the label histogram
+    with pytest.raises(RuntimeError, match="differ"):
+        mireg.pair_metrics(fd.unsqueeze(0), wd[:32].unsqueeze(0))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mireg.MSE(f[0, 0], w[0, 0])
