@@ -152,6 +152,22 @@ int mireg_pair_metrics(const float* fixed, const float* warped, double* sums, do
 int mireg_mutual_info(const float* fixed, const float* warped, int* joint, int* marg, double* out, int B, long n, int bins,
                       float scale, hipStream_t stream);
 
+/* ---- K16-K18: the FlowNet2 stack's glue layers (flownet2/models.py:40-88,136-180) ----
+ * Planar fp32 (B,C,H,W).  Resample2d and ChannelNorm are EXTERNAL custom layers of NVIDIA/flownet2-pytorch (sources absent
+ * from the reference tree, unpinned): published definitions, parity unpinned.
+ *   resample2d: out = bilinear(src, x + flow_x, y + flow_y) with the four tap indices clamped to the border; backward writes
+ *               gflow (overwrite) and ADDS into gsrc with fp32 atomics (zero it first); either may be NULL.
+ *   channelnorm: out[b,0] = sqrt(sum_c in[b,c]^2); backward gin = gout * in / (out + 1e-9).
+ *   upsample_nearest: nn.Upsample(scale_factor=k, mode='nearest') over NC planes; backward != 0: in = gradient of the
+ *               (H*k, W*k) tensor, out = gradient of the (H, W) tensor. */
+int mireg_resample2d_fwd(const float* src, const float* flow, float* out, int B, int C, int H, int W, hipStream_t stream);
+int mireg_resample2d_bwd(const float* src, const float* flow, const float* gout, float* gsrc, float* gflow, int B, int C, int H,
+                         int W, hipStream_t stream);
+int mireg_channelnorm_fwd(const float* in, float* out, int B, int C, long npix, hipStream_t stream);
+int mireg_channelnorm_bwd(const float* in, const float* out, const float* gout, float* gin, int B, int C, long npix,
+                          hipStream_t stream);
+int mireg_upsample_nearest(const float* in, float* out, long NC, int H, int W, int k, int backward, hipStream_t stream);
+
 /* ---- K1-K4: implicit-GEMM convolution family on MFMA ------------------------------------- */
 /* One descriptor drives three contractions (all NHWC, pixel stride `ld` in elements, so producers
  * write straight into channel slices of concat buffers -- replaces torch.cat, FlowNetS.py:64-79):

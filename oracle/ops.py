@@ -339,6 +339,33 @@ def pwc_warp(x: torch.Tensor, flo: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------
+# the FlowNet2 stack's external custom layers (flownet2/models.py:40-88,136-180).
+# NVIDIA/flownet2-pytorch resample2d_package / channelnorm_package are absent from the reference tree and unpinned:
+# restated from their published definitions -- PARITY UNPINNED (no reference-run fixture exists for these two).
+# ----------------------------------------------------------------------------
+def resample2d(src: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
+    """out[b,c,y,x] = bilinear(src[b,c], x + flow_x, y + flow_y); the four tap indices are clamped to the border."""
+    B, C, H, W = src.shape
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=F32), torch.arange(W, dtype=F32), indexing="ij")
+    xf, yf = xx + flow[:, 0], yy + flow[:, 1]
+    x0, y0 = torch.floor(xf), torch.floor(yf)
+    a, b = (xf - x0).unsqueeze(1), (yf - y0).unsqueeze(1)
+    xl, xr = x0.long().clamp(0, W - 1), (x0.long() + 1).clamp(0, W - 1)
+    yt, yb = y0.long().clamp(0, H - 1), (y0.long() + 1).clamp(0, H - 1)
+    flat = src.reshape(B, C, -1)
+
+    def at(yi, xi):
+        return torch.gather(flat, 2, (yi * W + xi).reshape(B, 1, -1).expand(B, C, -1)).reshape(B, C, H, W)
+
+    return (1 - a) * (1 - b) * at(yt, xl) + a * (1 - b) * at(yt, xr) + (1 - a) * b * at(yb, xl) + a * b * at(yb, xr)
+
+
+def channelnorm(x: torch.Tensor) -> torch.Tensor:
+    """sqrt(sum_c x^2) keeping a singleton channel; the layer's backward divides by (norm + 1e-9)."""
+    return torch.sqrt((x * x).sum(dim=1, keepdim=True))
+
+
+# ----------------------------------------------------------------------------
 # SURVEY section 8(f) rank 4: per-sample evaluation metrics (utils.py:41-59)
 # ----------------------------------------------------------------------------
 def mse(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
