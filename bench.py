@@ -257,7 +257,8 @@ def main():
                 t_m = (time.perf_counter() - t0) / n_ev
                 ev_line["with_metrics"] = {"pairs_per_s": round(args.batch / t_m, 1), "ms_per_batch": round(t_m * 1e3, 3),
                                            "mean_mse": float(evm["mse"].mean()), "mean_psnr": float(evm["psnr"].mean()),
-                                           "mean_corr": float(evm["corr"].mean()), "mean_mi": float(evm["mi"].mean())}
+                                           "mean_corr": float(evm["corr"].mean()), "mean_mi": float(evm["mi"].mean()),
+                                           "mean_ssim": float(evm["ssim"].mean()) if "ssim" in evm else None}
         except Exception as e:
             ev_line = {"error": repr(e)}
 

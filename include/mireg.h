@@ -151,6 +151,10 @@ int mireg_dice(const float* y_true, const float* y_pred, float* counts, float* d
 int mireg_pair_metrics(const float* fixed, const float* warped, double* sums, double* out, int B, long n, hipStream_t stream);
 int mireg_mutual_info(const float* fixed, const float* warped, int* joint, int* marg, double* out, int B, long n, int bins,
                       float scale, hipStream_t stream);
+/* inference.py:70-71: skimage.metrics.structural_similarity(a, b, data_range) with its defaults -- win_size x win_size uniform
+ * window (7), sample covariance, K1 = 0.01, K2 = 0.03, mean over the map cropped by (win_size-1)/2 per side; one float64 per
+ * (H, W) sample.  skimage is absent from this image and unpinned in the reference: published definition, parity unpinned. */
+int mireg_ssim(const float* a, const float* b, double* out, int B, int H, int W, int win_size, float data_range, hipStream_t stream);
 
 /* ---- K16-K18: the FlowNet2 stack's glue layers (flownet2/models.py:40-88,136-180) ----
  * Planar fp32 (B,C,H,W).  Resample2d and ChannelNorm are EXTERNAL custom layers of NVIDIA/flownet2-pytorch (sources absent

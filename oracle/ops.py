@@ -389,6 +389,23 @@ def pearson(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
     return (vx * vy).sum() / torch.sqrt((vx * vx).sum() * (vy * vy).sum())
 
 
+def ssim(im1: torch.Tensor, im2: torch.Tensor, data_range: float = 1.0, win_size: int = 7) -> float:
+    """inference.py:70-71: skimage.metrics.structural_similarity(im1, im2, data_range=1.0) with its defaults (skimage absent here
+    and unpinned -- PARITY UNPINNED): the published algorithm on the same scipy.ndimage.uniform_filter skimage calls -- 7x7 uniform
+    window, sample covariance, K1 = 0.01, K2 = 0.03, float32 maps, float64 mean of the map cropped by 3 pixels per side."""
+    from scipy.ndimage import uniform_filter
+    x, y = im1.numpy().astype(np.float32), im2.numpy().astype(np.float32)
+    npix = win_size ** 2
+    cov_norm = npix / (npix - 1)
+    ux, uy = uniform_filter(x, size=win_size), uniform_filter(y, size=win_size)
+    uxx, uyy, uxy = uniform_filter(x * x, size=win_size), uniform_filter(y * y, size=win_size), uniform_filter(x * y, size=win_size)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+    pad = (win_size - 1) // 2
+    return float(s[pad:-pad, pad:-pad].mean(dtype=np.float64))
+
+
 def mutual_info(fixed: torch.Tensor, warped: torch.Tensor, scale: float = 1500.0) -> float:
     """utils.py:52-55: sklearn.metrics.mutual_info_score(round(fixed*1500), round(warped*1500)); restated from its published
     definition sum_ij n_ij/N * log(N n_ij / (a_i b_j)) (natural log); tests also call sklearn's own function when importable."""

@@ -4,6 +4,7 @@
 //   PSNR utils.py:45-49    100 if mse < 1e-10 else 10*log10(1/mse)
 //   CORR utils.py:58-59    Pearson correlation of the flattened images (torchmetrics.pearson_corrcoef)
 //   MI   utils.py:52-55    sklearn.metrics.mutual_info_score of round(x*1500) labels (natural log)
+//   SSIM inference.py:70-71 skimage.metrics.structural_similarity(a, b, data_range=1.0), defaults (7x7 uniform window)
 // One launch covers the whole batch for the moment-based three; MI counts into a dense joint table per sample (bins^2 int32),
 // sums log(N n_ij / (a_i b_j)) over the PIXELS (not the cells) and zeroes the touched counters again: three launches per batch.
 #include "mireg_common.h"
@@ -134,6 +135,49 @@ mi_clear_kernel(const float* __restrict__ fixed, const float* __restrict__ warpe
   }
 }
 
+
+// SSIM as skimage.metrics.structural_similarity(a, b, data_range=R) computes it with its defaults (inference.py:70-71): 7x7
+// uniform window, sample covariance (x 49/48), K1 = 0.01, K2 = 0.03, mean of the SSIM map cropped by 3 pixels per side
+// (only windows that lie fully inside the image count, so the filter's border mode never matters).  One thread per
+// interior pixel; window sums in double, rounded to float like the float32 filter output, map arithmetic in float.
+__global__ void __launch_bounds__(kThreads)
+ssim_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ out, int H, int W, int win, float c1,
+            float c2) {
+  __shared__ double red[kThreads / 64];
+  const int s = blockIdx.y, pad = (win - 1) / 2;
+  const float* x = a + (long)s * H * W;
+  const float* y = b + (long)s * H * W;
+  const int ih = H - 2 * pad, iw = W - 2 * pad;
+  const long cnt = (long)ih * iw;
+  const double np_ = (double)win * win;
+  const float cov_norm = (float)(np_ / (np_ - 1.0));
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long)gridDim.x * blockDim.x) {
+    const int py = (int)(i / iw), px = (int)(i - (long)py * iw);      // window = rows py..py+win-1, cols px..px+win-1
+    double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int dy = 0; dy < win; ++dy) {
+      const float* rx = x + (long)(py + dy) * W + px;
+      const float* ry = y + (long)(py + dy) * W + px;
+      for (int dx = 0; dx < win; ++dx) {
+        const double u = rx[dx], v = ry[dx];
+        sx += u; sy += v; sxx += u * u; syy += v * v; sxy += u * v;
+      }
+    }
+    const float ux = (float)(sx / np_), uy = (float)(sy / np_), uxx = (float)(sxx / np_), uyy = (float)(syy / np_), uxy = (float)(sxy / np_);
+    const float vx = cov_norm * (uxx - ux * ux), vy = cov_norm * (uyy - uy * uy), vxy = cov_norm * (uxy - ux * uy);
+    const float A1 = 2.f * ux * uy + c1, A2 = 2.f * vxy + c2, B1 = ux * ux + uy * uy + c1, B2 = vx + vy + c2;
+    acc += (double)((A1 * A2) / (B1 * B2));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kThreads / 64; ++k) t += red[k];
+    atomicAdd(out + s, t / (double)cnt);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -159,6 +203,18 @@ int mireg_mutual_info(const float* fixed, const float* warped, int* joint, int* 
   hipLaunchKernelGGL(mi_count_kernel, grid, dim3(kThreads), 0, stream, fixed, warped, joint, marg, n, bins, scale);
   hipLaunchKernelGGL(mi_sum_kernel, grid, dim3(kThreads), 0, stream, fixed, warped, joint, marg, out, n, bins, scale);
   hipLaunchKernelGGL(mi_clear_kernel, grid, dim3(kThreads), 0, stream, fixed, warped, joint, marg, n, bins, scale);
+  MIREG_LAUNCH_RET();
+}
+
+
+int mireg_ssim(const float* a, const float* b, double* out, int B, int H, int W, int win_size, float data_range, hipStream_t stream) {
+  MIREG_CHECK_ARG(a && b && out && B > 0 && win_size >= 3 && (win_size & 1) && H >= win_size && W >= win_size && data_range > 0.f);
+  if (hipMemsetAsync(out, 0, (size_t)B * sizeof(double), stream) != hipSuccess) return MIREG_ERR_LAUNCH;
+  const long cnt = (long)(H - win_size + 1) * (W - win_size + 1);
+  long g = (cnt + kThreads - 1) / kThreads;
+  if (g > 512) g = 512;
+  const float c1 = (0.01f * data_range) * (0.01f * data_range), c2 = (0.03f * data_range) * (0.03f * data_range);
+  hipLaunchKernelGGL(ssim_kernel, dim3((unsigned)g, B), dim3(kThreads), 0, stream, a, b, out, H, W, win_size, c1, c2);
   MIREG_LAUNCH_RET();
 }
 

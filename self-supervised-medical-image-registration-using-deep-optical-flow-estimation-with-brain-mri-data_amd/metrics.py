@@ -23,7 +23,7 @@ def _as_batch(fixed: torch.Tensor, warped: torch.Tensor):
 
 
 def pair_metrics(fixed: torch.Tensor, warped: torch.Tensor, mutual_info: bool = True) -> Dict[str, torch.Tensor]:
-    """fixed / warped: (B, ...) batches -> {"mse", "psnr", "corr"[, "mi"]}: float64 tensors of shape (B,), one value per sample
+    """fixed / warped: (B, ...) batches -> {"mse", "psnr", "corr"[, "ssim"][, "mi"]}: float64 tensors of shape (B,), one value per sample
     (what inference.py:66-75 feeds its running averages with)."""
     f, w = _as_batch(fixed, warped)
     B = f.shape[0]
@@ -33,6 +33,8 @@ def pair_metrics(fixed: torch.Tensor, warped: torch.Tensor, mutual_info: bool = 
     out = torch.empty(B, 3, device=dev, dtype=torch.float64)
     _lib.call("mireg_pair_metrics", f.data_ptr(), w.data_ptr(), sums.data_ptr(), out.data_ptr(), B, n, st)
     res = {"mse": out[:, 0], "psnr": out[:, 1], "corr": out[:, 2]}
+    if f.dim() >= 3 and f.numel() == B * f.shape[-2] * f.shape[-1] and min(f.shape[-2:]) >= 7:
+        res["ssim"] = ssim_batch(f, w)
     if mutual_info:
         key = (dev, B)
         if key not in _MI_WS:                                  # zeroed once; the kernels leave the tables clean
@@ -45,6 +47,23 @@ def pair_metrics(fixed: torch.Tensor, warped: torch.Tensor, mutual_info: bool = 
                   MI_SCALE, st)
         res["mi"] = mi
     return res
+
+
+def ssim_batch(a: torch.Tensor, b: torch.Tensor, data_range: float = 1.0, win_size: int = 7) -> torch.Tensor:
+    """a / b: (B, H, W) or (B, 1, H, W) -> (B,) float64: skimage.metrics.structural_similarity(a[i], b[i], data_range=...) with
+    its defaults, as inference.py:70-71 calls it for the image pair and for the segmentation pair."""
+    a, b = _as_batch(a, b)
+    B, H, W = a.shape[0], a.shape[-2], a.shape[-1]
+    if a.numel() != B * H * W:
+        raise RuntimeError(f"ssim_batch expects one channel per sample, got {tuple(a.shape)}")
+    out = torch.empty(B, device=a.device, dtype=torch.float64)
+    _lib.call("mireg_ssim", a.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, int(win_size), float(data_range), _stream())
+    return out
+
+
+def structural_similarity(im1: torch.Tensor, im2: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """Drop-in for the call at reference inference.py:70-71 on one (H, W) pair."""
+    return ssim_batch(im1.unsqueeze(0), im2.unsqueeze(0), data_range)[0]
 
 
 def _single(fixed: torch.Tensor, warped: torch.Tensor, key: str) -> torch.Tensor:

@@ -44,3 +44,20 @@ def test_reference_named_single_sample_calls_and_edge_cases():
         mireg.pair_metrics(fd.unsqueeze(0), wd[:32].unsqueeze(0))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mireg.MSE(f[0, 0], w[0, 0])
+
+
+def test_ssim_images_and_label_maps():
+    """inference.py:70-71 calls SSIM on the image pair and on the (float) segmentation pair."""
+    import mireg
+    f, w = _pair(3, 96, 11)
+    got = mireg.ssim_batch(f.to(DEV), w.to(DEV))
+    for b in range(3):
+        assert abs(got[b].item() - oops.ssim(f[b, 0], w[b, 0])) < 2e-5
+    seg_a = torch.floor(f[0, 0] * 4).clamp(0, 3)
+    seg_b = torch.floor(w[0, 0] * 4).clamp(0, 3)
+    assert abs(mireg.structural_similarity(seg_a.to(DEV), seg_b.to(DEV)).item() - oops.ssim(seg_a, seg_b)) < 2e-5
+    assert abs(mireg.structural_similarity(seg_a.to(DEV), seg_a.to(DEV)).item() - 1.0) < 1e-6          # float32 maps
+    r = mireg.pair_metrics(f.to(DEV), w.to(DEV))
+    assert "ssim" in r and abs(r["ssim"][1].item() - got[1].item()) < 1e-12
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        mireg.ssim_batch(torch.zeros(1, 5, 5, device=DEV), torch.zeros(1, 5, 5, device=DEV))
