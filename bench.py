@@ -259,8 +259,23 @@ def main():
                                            "mean_mse": float(evm["mse"].mean()), "mean_psnr": float(evm["psnr"].mean()),
                                            "mean_corr": float(evm["corr"].mean()), "mean_mi": float(evm["mi"].mean()),
                                            "mean_ssim": float(evm["ssim"].mean()) if "ssim" in evm else None}
+            # on-device elastic deformation of the batch (the Rand2DElasticd step of the reference's CPU pipeline, dataset.py:78)
+            from mireg.synth import elastic_deform
+            gaug = torch.Generator().manual_seed(3)
+            ctrl = ((torch.rand(args.batch, 2, args.size // 16 + 1, args.size // 16 + 1, generator=gaug) * 2 - 1) * 8).to(dev)
+            fx, sg = xs[:, 0:1].contiguous(), ss[:, 0:1].contiguous().float()
+            for _ in range(3):
+                elastic_deform(fx, sg, ctrl)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                elastic_deform(fx, sg, ctrl)
+            torch.cuda.synchronize()
+            t_a = (time.perf_counter() - t0) / 20
+            ev_line["augment"] = {"pairs_per_s": round(args.batch / t_a, 1), "us_per_batch": round(t_a * 1e6, 1),
+                                  "note": "bicubic control-grid field + bicubic image / nearest label resampling, eager"}
         except Exception as e:
-            ev_line = {"error": repr(e)}
+            ev_line = dict(ev_line or {}, error=repr(e))
 
     # ---- 3-D leg (north_star "128^3 volumes"): the reference's only 3-D model, affmodel (models.py:156-191), forward +
     # affine grid / trilinear sampling + Affloss on synthetic 128^3 pairs, B = 8 (BASELINE configs[4] batch) ----------------

@@ -172,6 +172,15 @@ int mireg_channelnorm_bwd(const float* in, const float* out, const float* gout, 
                           hipStream_t stream);
 int mireg_upsample_nearest(const float* in, float* out, long NC, int H, int W, int k, int backward, hipStream_t stream);
 
+/* ---- on-device elastic deformation of a batch (the Rand2DElasticd step of the reference's CPU data pipeline, dataset.py:78,
+ * 150-152,205).  Planar fp32.  mireg_resize_bicubic_fwd = F.interpolate(mode='bicubic',
+ * align_corners=True) over NC planes (control grid -> dense displacement, in pixels).  mireg_elastic_sample: out_img =
+ * clamp(grid_sample(img, identity + disp, bicubic, zeros, align_corners=True), 0, 1), out_seg = the same grid with nearest
+ * neighbour; the grid is linspace(-1,1)[i] + disp*2/size as the generator builds it; img or seg may be NULL. */
+int mireg_resize_bicubic_fwd(const float* in, float* out, long NC, int H, int W, int h, int w, hipStream_t stream);
+int mireg_elastic_sample(const float* img, const float* seg, const float* disp, float* out_img, float* out_seg, int B, int C, int Cs,
+                         int H, int W, hipStream_t stream);
+
 /* ---- K1-K4: implicit-GEMM convolution family on MFMA ------------------------------------- */
 /* One descriptor drives three contractions (all NHWC, pixel stride `ld` in elements, so producers
  * write straight into channel slices of concat buffers -- replaces torch.cat, FlowNetS.py:64-79):

@@ -38,3 +38,30 @@ def make_pairs(n: int, size: int = 256, seed: int = 6, magnitude=(0.0, 0.5), spa
     moving = F.grid_sample(fixed, grid, mode="bicubic", padding_mode="zeros", align_corners=True).clamp(0, 1)
     seg_m = F.grid_sample(seg_f, grid, mode="nearest", padding_mode="zeros", align_corners=True)
     return torch.cat((fixed, moving), 1).contiguous(), torch.cat((seg_f, seg_m), 1).contiguous()
+
+
+def elastic_deform(images: torch.Tensor, segs, ctrl: torch.Tensor):
+    """On-device elastic deformation (the per-batch Rand2DElasticd step, reference dataset.py:78,150-152,205): images (B,C,H,W)
+    in [0,1], segs (B,Cs,H,W) label maps or None, ctrl (B,2,gh,gw) control-grid displacements in pixels -> (warped images,
+    warped segs).  Same arithmetic as make_pairs above (bicubic field, bicubic image / nearest label resampling, zero padding,
+    align_corners=True) on the HIP kernels of csrc/augment.hip; no CPU fallback."""
+    from . import _lib
+    from .ops import _need_gpu, _stream
+    _need_gpu(images, ctrl)
+    B, C, H, W = images.shape
+    if ctrl.shape[0] != B or ctrl.shape[1] != 2:
+        raise RuntimeError(f"elastic_deform: ctrl {tuple(ctrl.shape)} does not match a batch of {B}")
+    images, ctrl = images.contiguous(), ctrl.contiguous()
+    st = _stream()
+    disp = torch.empty(B, 2, H, W, device=images.device, dtype=torch.float32)
+    _lib.call("mireg_resize_bicubic_fwd", ctrl.data_ptr(), disp.data_ptr(), B * 2, ctrl.shape[2], ctrl.shape[3], H, W, st)
+    out = torch.empty_like(images)
+    out_seg = None
+    if segs is not None:
+        _need_gpu(segs)
+        segs = segs.contiguous()
+        out_seg = torch.empty_like(segs)
+    _lib.call("mireg_elastic_sample", images.data_ptr(), segs.data_ptr() if segs is not None else None, disp.data_ptr(),
+              out.data_ptr(), out_seg.data_ptr() if out_seg is not None else None, B, C, segs.shape[1] if segs is not None else 0,
+              H, W, st)
+    return out, out_seg
