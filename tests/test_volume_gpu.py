@@ -202,3 +202,50 @@ def test_flownets3d_non_cubic_volume_eval():
         assert (a.cpu() - b).abs().max().item() < 1e-3 * max(1.0, b.abs().max().item())
     with pytest.raises(RuntimeError, match="divisible by 64"):
         m(torch.zeros(1, 2, 64, 96, 64, device=DEV))
+
+
+# ---- data parallelism of the volume path: torch DistributedDataParallel over the parameter gradients the HIP backward returns ----
+def _ddp3d_worker(rank, world, port, ret):
+    """Two ranks share cuda:0 over gloo (RCCL refuses two ranks on one device).  DDP averages the gradients that the
+    predictor's autograd function hands back; BatchNorm statistics stay per rank (as in the 2-D trainer)."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mireg
+    torch.cuda.set_device(0)
+    m = mireg.opticalFlowReg3d(precision="fp32", width_div=8)
+    m.load_state_dict(_fresh_state(None))
+    m = m.to(DEV).train()
+    ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], broadcast_buffers=False)
+    x = nets.analytic_input((2, 2, 64, 64, 64), seed=30 + rank).to(DEV)
+    flows, warped = ddp(x)
+    mireg.OFEloss3d(flows, warped, x[:, 0:1])[3].backward()
+    torch.cuda.synchronize()
+    torch.save({k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}, os.path.join(ret, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flownets3d_ddp_two_ranks_on_one_gpu():
+    import os, socket, tempfile
+    import torch.multiprocessing as mp
+    import mireg
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    tmp = tempfile.mkdtemp(prefix="mireg_ddp3d_")
+    mp.spawn(_ddp3d_worker, args=(2, port, tmp), nprocs=2, join=True)
+    g0, g1 = torch.load(os.path.join(tmp, "rank0.pt")), torch.load(os.path.join(tmp, "rank1.pt"))
+    # single-process gradients of each rank's batch, averaged: what the all-reduce must have produced on both ranks
+    want = None
+    for rank in range(2):
+        m = mireg.opticalFlowReg3d(precision="fp32", width_div=8)
+        m.load_state_dict(_fresh_state(None))
+        m = m.to(DEV).train()
+        x = nets.analytic_input((2, 2, 64, 64, 64), seed=30 + rank).to(DEV)
+        flows, warped = m(x)
+        mireg.OFEloss3d(flows, warped, x[:, 0:1])[3].backward()
+        g = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+        want = g if want is None else {k: 0.5 * (want[k] + g[k]) for k in g}
+    for k in want:
+        assert torch.equal(g0[k], g1[k]), k                                     # both ranks hold the same reduced gradient
+        assert (g0[k] - want[k]).abs().max().item() <= 1e-5 * max(1.0, want[k].abs().max().item()), k
