@@ -1,5 +1,5 @@
 #include "../../include/mireg.h"
 extern "C" {
-int mireg_version(void) { return 1; }
+int mireg_version(void) { return 2; }
 const char* mireg_arch(void) { return "gfx950"; }
 }
