@@ -155,6 +155,10 @@ int mireg_mutual_info(const float* fixed, const float* warped, int* joint, int* 
  * window (7), sample covariance, K1 = 0.01, K2 = 0.03, mean over the map cropped by (win_size-1)/2 per side; one float64 per
  * (H, W) sample.  skimage is absent from this image and unpinned in the reference: published definition, parity unpinned. */
 int mireg_ssim(const float* a, const float* b, double* out, int B, int H, int W, int win_size, float data_range, hipStream_t stream);
+/* utils.py:187-199 modified_hausdorff(A, B): max(mean_j min_i |A_i - B_j|, mean_i min_j |A_i - B_j|) for two point sets of
+ * (row, col) float pairs (the contour points utils.py:154-170 extracts with skimage.measure.find_contours -- that extraction is
+ * not part of this library); work = nA + nB floats; out = one float64. */
+int mireg_modified_hausdorff(const float* A, int nA, const float* B, int nB, float* work, double* out, hipStream_t stream);
 
 /* ---- K16-K18: the FlowNet2 stack's glue layers (flownet2/models.py:40-88,136-180) ----
  * Planar fp32 (B,C,H,W).  Resample2d and ChannelNorm are EXTERNAL custom layers of NVIDIA/flownet2-pytorch (sources absent
@@ -180,6 +184,10 @@ int mireg_upsample_nearest(const float* in, float* out, long NC, int H, int W, i
 int mireg_resize_bicubic_fwd(const float* in, float* out, long NC, int H, int W, int h, int w, hipStream_t stream);
 int mireg_elastic_sample(const float* img, const float* seg, const float* disp, float* out_img, float* out_seg, int B, int C, int Cs,
                          int H, int W, hipStream_t stream);
+/* the RandAffined step (dataset.py:79,151): F.grid_sample(x, F.affine_grid(theta, x.size())) with torch's defaults
+ * (align_corners=False, zeros): bilinear for img, nearest for seg; theta (B,2,3) row-major; img or seg may be NULL. */
+int mireg_affine_sample2d(const float* img, const float* seg, const float* theta, float* out_img, float* out_seg, int B, int C,
+                          int Cs, int H, int W, hipStream_t stream);
 
 /* ---- K1-K4: implicit-GEMM convolution family on MFMA ------------------------------------- */
 /* One descriptor drives three contractions (all NHWC, pixel stride `ld` in elements, so producers

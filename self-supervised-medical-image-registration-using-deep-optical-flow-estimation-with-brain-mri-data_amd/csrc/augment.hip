@@ -108,6 +108,46 @@ elastic_sample_kernel(const float* __restrict__ img, const float* __restrict__ s
   }
 }
 
+
+// affine resampling of a batch (the RandAffined step, dataset.py:79,151): F.grid_sample(x, F.affine_grid(theta, x.size())) with
+// torch's defaults (align_corners=False): bilinear + zeros for images, nearest + zeros for label maps.  theta: (B,2,3).
+__global__ void __launch_bounds__(kThreads)
+affine_sample2d_kernel(const float* __restrict__ img, const float* __restrict__ seg, const float* __restrict__ theta,
+                       float* __restrict__ out_img, float* __restrict__ out_seg, int B, int C, int Cs, int H, int W) {
+  const long npix = (long)H * W, total = (long)B * npix;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / npix);
+    const long p = i - (long)b * npix;
+    const int y = (int)(p / W), x = (int)(p - (long)y * W);
+    const float* t = theta + b * 6;
+    const float bx = (2.f * x + 1.f) / (float)W - 1.f, by = (2.f * y + 1.f) / (float)H - 1.f;
+    const float gx = t[0] * bx + t[1] * by + t[2], gy = t[3] * bx + t[4] * by + t[5];
+    const float px = ((gx + 1.f) * (float)W - 1.f) / 2.f, py = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    if (img) {
+      const float fx = floorf(px), fy = floorf(py);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float wx1 = px - fx, wy1 = py - fy;
+      for (int c = 0; c < C; ++c) {
+        const float* s = img + ((long)b * C + c) * npix;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int xi = x0 + (k & 1), yi = y0 + (k >> 1);
+          if (xi < 0 || xi >= W || yi < 0 || yi >= H) continue;
+          acc += s[(long)yi * W + xi] * ((k & 1) ? wx1 : 1.f - wx1) * ((k >> 1) ? wy1 : 1.f - wy1);
+        }
+        out_img[((long)b * C + c) * npix + p] = acc;
+      }
+    }
+    if (seg) {
+      const int xn = (int)nearbyintf(px), yn = (int)nearbyintf(py);
+      const bool ok = xn >= 0 && xn < W && yn >= 0 && yn < H;
+      for (int c = 0; c < Cs; ++c)
+        out_seg[((long)b * Cs + c) * npix + p] = ok ? seg[((long)b * Cs + c) * npix + (long)yn * W + xn] : 0.f;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -125,6 +165,16 @@ int mireg_elastic_sample(const float* img, const float* seg, const float* disp, 
   MIREG_CHECK_ARG((!img || (out_img && C > 0)) && (!seg || (out_seg && Cs > 0)));
   hipLaunchKernelGGL(elastic_sample_kernel, dim3(grid_for((long)B * H * W)), dim3(kThreads), 0, stream, img, seg, disp, out_img, out_seg,
                      B, C, Cs, H, W);
+  MIREG_LAUNCH_RET();
+}
+
+
+int mireg_affine_sample2d(const float* img, const float* seg, const float* theta, float* out_img, float* out_seg, int B, int C,
+                          int Cs, int H, int W, hipStream_t stream) {
+  MIREG_CHECK_ARG(theta && (img || seg) && B > 0 && H > 0 && W > 0);
+  MIREG_CHECK_ARG((!img || (out_img && C > 0)) && (!seg || (out_seg && Cs > 0)));
+  hipLaunchKernelGGL(affine_sample2d_kernel, dim3(grid_for((long)B * H * W)), dim3(kThreads), 0, stream, img, seg, theta, out_img,
+                     out_seg, B, C, Cs, H, W);
   MIREG_LAUNCH_RET();
 }
 

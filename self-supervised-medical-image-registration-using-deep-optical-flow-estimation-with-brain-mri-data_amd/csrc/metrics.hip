@@ -178,6 +178,44 @@ ssim_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __
   }
 }
 
+
+// modified Hausdorff distance of two point sets (utils.py:187-199, Dubuisson & Jain): D = cdist(A, B);
+// max(mean_j min_i D_ij, mean_i min_j D_ij).  Thread per point: nearest neighbour in the other set (sets are contour
+// points, a few thousand each), then a one-block mean / max.  Points are (row, col) pairs, any float values.
+__global__ void __launch_bounds__(kThreads)
+mhd_nearest_kernel(const float* __restrict__ A, int nA, const float* __restrict__ Bp, int nB, float* __restrict__ work) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nA + nB) return;
+  const bool fromA = i < nA;
+  const float* me = fromA ? A + 2 * i : Bp + 2 * (i - nA);
+  const float* other = fromA ? Bp : A;
+  const int n = fromA ? nB : nA;
+  const float y = me[0], x = me[1];
+  float best = 3.4e38f;
+  for (int j = 0; j < n; ++j) {
+    const float dy = other[2 * j] - y, dx = other[2 * j + 1] - x;
+    best = fminf(best, dy * dy + dx * dx);
+  }
+  work[i] = sqrtf(best);
+}
+
+__global__ void __launch_bounds__(kThreads)
+mhd_finalize_kernel(const float* __restrict__ work, int nA, int nB, double* __restrict__ out) {
+  __shared__ double red[2][kThreads / 64];
+  double sa = 0.0, sb = 0.0;
+  for (int i = threadIdx.x; i < nA; i += blockDim.x) sa += (double)work[i];
+  for (int i = threadIdx.x; i < nB; i += blockDim.x) sb += (double)work[nA + i];
+  sa = wave_sum(sa); sb = wave_sum(sb);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sa; red[1][threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int k = 0; k < kThreads / 64; ++k) { ta += red[0][k]; tb += red[1][k]; }
+    const double rhd = ta / (double)nA, fhd = tb / (double)nB;      // rows of D belong to A, columns to B
+    out[0] = fhd > rhd ? fhd : rhd;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -215,6 +253,14 @@ int mireg_ssim(const float* a, const float* b, double* out, int B, int H, int W,
   if (g > 512) g = 512;
   const float c1 = (0.01f * data_range) * (0.01f * data_range), c2 = (0.03f * data_range) * (0.03f * data_range);
   hipLaunchKernelGGL(ssim_kernel, dim3((unsigned)g, B), dim3(kThreads), 0, stream, a, b, out, H, W, win_size, c1, c2);
+  MIREG_LAUNCH_RET();
+}
+
+
+int mireg_modified_hausdorff(const float* A, int nA, const float* B, int nB, float* work, double* out, hipStream_t stream) {
+  MIREG_CHECK_ARG(A && B && work && out && nA > 0 && nB > 0);
+  hipLaunchKernelGGL(mhd_nearest_kernel, dim3((nA + nB + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, A, nA, B, nB, work);
+  hipLaunchKernelGGL(mhd_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, work, nA, nB, out);
   MIREG_LAUNCH_RET();
 }
 

@@ -88,3 +88,16 @@ def CORR(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
 def MI(fixed: torch.Tensor, warped: torch.Tensor) -> torch.Tensor:
     """Drop-in for reference utils.MI (utils.py:52-55)."""
     return _single(fixed, warped, "mi")
+
+
+def modified_hausdorff(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference utils.modified_hausdorff (utils.py:187-199) on two (n, 2) point sets (device tensors): float64
+    scalar.  The contour extraction in front of it (utils.py:154-170, skimage.measure.find_contours) is not part of mireg."""
+    _need_gpu(A.float(), B.float())
+    A, B = A.float().contiguous(), B.float().contiguous()
+    if A.dim() != 2 or B.dim() != 2 or A.shape[1] != 2 or B.shape[1] != 2 or A.shape[0] == 0 or B.shape[0] == 0:
+        raise RuntimeError(f"modified_hausdorff expects two non-empty (n, 2) point sets, got {tuple(A.shape)} and {tuple(B.shape)}")
+    work = torch.empty(A.shape[0] + B.shape[0], device=A.device, dtype=torch.float32)
+    out = torch.empty(1, device=A.device, dtype=torch.float64)
+    _lib.call("mireg_modified_hausdorff", A.data_ptr(), A.shape[0], B.data_ptr(), B.shape[0], work.data_ptr(), out.data_ptr(), _stream())
+    return out[0]

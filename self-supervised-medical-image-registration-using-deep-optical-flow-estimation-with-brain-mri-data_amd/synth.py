@@ -65,3 +65,27 @@ def elastic_deform(images: torch.Tensor, segs, ctrl: torch.Tensor):
               out.data_ptr(), out_seg.data_ptr() if out_seg is not None else None, B, C, segs.shape[1] if segs is not None else 0,
               H, W, st)
     return out, out_seg
+
+
+
+def affine_deform(images: torch.Tensor, segs, theta: torch.Tensor):
+    """On-device affine resampling (the per-batch RandAffined step, reference dataset.py:79,151): images (B,C,H,W), segs
+    (B,Cs,H,W) or None, theta (B,2,3) -> F.grid_sample(x, F.affine_grid(theta, x.size())) with torch's defaults, bilinear for
+    the images and nearest for the label maps; no CPU fallback."""
+    from . import _lib
+    from .ops import _need_gpu, _stream
+    _need_gpu(images, theta)
+    B, C, H, W = images.shape
+    if tuple(theta.shape) != (B, 2, 3):
+        raise RuntimeError(f"affine_deform: theta {tuple(theta.shape)} does not match a batch of {B}")
+    images, theta = images.contiguous(), theta.contiguous()
+    out = torch.empty_like(images)
+    out_seg = None
+    if segs is not None:
+        _need_gpu(segs)
+        segs = segs.contiguous()
+        out_seg = torch.empty_like(segs)
+    _lib.call("mireg_affine_sample2d", images.data_ptr(), segs.data_ptr() if segs is not None else None, theta.data_ptr(),
+              out.data_ptr(), out_seg.data_ptr() if out_seg is not None else None, B, C, segs.shape[1] if segs is not None else 0,
+              H, W, _stream())
+    return out, out_seg

@@ -40,3 +40,19 @@ def test_elastic_deform_matches_the_cpu_generator_ops(size, spacing, mag):
     assert none is None and torch.equal(only_img, mov)
     with pytest.raises(RuntimeError, match="does not match"):
         elastic_deform(img.to(DEV), None, cd[:2])
+
+
+def test_affine_deform_matches_torch_affine_grid_sample():
+    from mireg.synth import affine_deform, make_pairs
+    x, s = make_pairs(3, 96, seed=5)
+    img, seg = x[:, 0:1].contiguous(), s[:, 0:1].contiguous()
+    g = torch.Generator().manual_seed(2)
+    theta = torch.eye(2, 3).repeat(3, 1, 1) + 0.2 * (torch.rand(3, 2, 3, generator=g) - 0.5)
+    grid = F.affine_grid(theta, list(img.shape), align_corners=False)
+    mov_ref = F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    seg_ref = F.grid_sample(seg, grid, mode="nearest", padding_mode="zeros", align_corners=False)
+    mov, sg = affine_deform(img.to(DEV), seg.to(DEV), theta.to(DEV))
+    assert (mov.cpu() - mov_ref).abs().max().item() < 2e-5
+    assert (sg.cpu() != seg_ref).float().mean().item() < 2e-4                   # nearest-neighbour ties only
+    with pytest.raises(RuntimeError, match="does not match"):
+        affine_deform(img.to(DEV), None, theta[:2].to(DEV))

@@ -61,3 +61,20 @@ def test_ssim_images_and_label_maps():
     assert "ssim" in r and abs(r["ssim"][1].item() - got[1].item()) < 1e-12
     with pytest.raises(RuntimeError, match="invalid argument"):
         mireg.ssim_batch(torch.zeros(1, 5, 5, device=DEV), torch.zeros(1, 5, 5, device=DEV))
+
+
+def test_modified_hausdorff_of_point_sets_vs_scipy():
+    """utils.py:187-199 on the reference's own dependency (scipy.spatial.distance.cdist)."""
+    import numpy as np
+    import mireg
+    from scipy.spatial.distance import cdist
+    rng = np.random.default_rng(5)
+    for na, nb in ((1, 1), (37, 5), (700, 913)):
+        A = rng.integers(0, 256, size=(na, 2)).astype(np.float32)
+        Bp = rng.integers(0, 256, size=(nb, 2)).astype(np.float32)
+        D = cdist(A, Bp)
+        want = max(np.mean(np.min(D, axis=0)), np.mean(np.min(D, axis=1)))
+        got = mireg.modified_hausdorff(torch.from_numpy(A).to(DEV), torch.from_numpy(Bp).to(DEV)).item()
+        assert abs(got - want) < 1e-5 * max(1.0, want), (na, nb, got, want)
+    with pytest.raises(RuntimeError, match="non-empty"):
+        mireg.modified_hausdorff(torch.zeros(0, 2, device=DEV), torch.zeros(3, 2, device=DEV))
