@@ -346,9 +346,12 @@ class OpticalFlowReg3d(nn.Module):
         super().__init__()
         self.predictor = FlowNetS3D(width_div)
 
-    def forward(self, x):
+    def forward(self, x, segs=None):
         flows = self.predictor(x)
-        return list(flows), [ops.stn3d(f, x[:, 1:2]) for f in flows]
+        warped = [ops.stn3d(f, x[:, 1:2]) for f in flows]
+        if segs is None:
+            return list(flows), warped
+        return list(flows), warped, ops.seg_round(ops.stn3d(flows[0].detach(), segs[:, 1:2].float()))
 
 
 def _hash_uniform(idx: torch.Tensor, salt: float) -> torch.Tensor:

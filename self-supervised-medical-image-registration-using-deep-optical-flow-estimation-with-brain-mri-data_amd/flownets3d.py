@@ -266,8 +266,8 @@ class FlowNetS3D(nn.Module):
 
 class opticalFlowReg3d(nn.Module):
     """reference models.opticalFlowReg (models.py:209-292) over volumes: `(x) -> (flows, warped)` with x = (B, 2, D, H, W) =
-    [fixed, moving]; every flow scale warps the moving volume (`stn3d`).  Segmentations ride the same warp:
-    `stn3d(flows[0], seg)` then mireg.seg_round / mireg.dice_average as in 2-D."""
+    [fixed, moving]; every flow scale warps the moving volume (`stn3d`); `forward(x, segs)` also returns the warped, rounded
+    moving segmentation for `mireg.dice_batch` / `mireg.dice_average` (dimension-agnostic), as the 2-D wrapper does."""
 
     def __init__(self, precision: str = "bf16", width_div: int = 1):
         super().__init__()
@@ -275,7 +275,14 @@ class opticalFlowReg3d(nn.Module):
 
     stn = staticmethod(stn3d)
 
-    def forward(self, x: torch.Tensor):
+    def forward(self, x: torch.Tensor, segs: torch.Tensor = None):
+        """-> (flows, warped) or, with segs = (B, 2, D, H, W) label volumes [fixed, moving], (flows, warped, warped_segs_int):
+        the moving labels ride the finest flow and are rounded / clipped to {0..3} on device (reference models.py:275-278,286)."""
         flows = self.predictor(x)
         moving = x[:, 1:2]
-        return list(flows), [stn3d(f, moving) for f in flows]
+        warped = [stn3d(f, moving) for f in flows]
+        if segs is None:
+            return list(flows), warped
+        from .ops import seg_round
+        wseg = seg_round(stn3d(flows[0].detach(), segs[:, 1:2].float()))
+        return list(flows), warped, wseg

@@ -249,3 +249,23 @@ def test_flownets3d_ddp_two_ranks_on_one_gpu():
     for k in want:
         assert torch.equal(g0[k], g1[k]), k                                     # both ranks hold the same reduced gradient
         assert (g0[k] - want[k]).abs().max().item() <= 1e-5 * max(1.0, want[k].abs().max().item()), k
+
+
+def test_flownets3d_warped_segmentation_dice_vs_oracle():
+    """Label volumes ride the finest flow (stn3d, round, clip) and Dice is taken per sample: GPU chain vs the CPU oracle."""
+    import mireg
+    x = nets.analytic_input((2, 2, 64, 64, 64), seed=15)
+    segs = torch.bucketize(x, torch.tensor([0.25, 0.5, 0.75])).float()          # 4 labels from intensity thresholds
+    o = _ref3d(8, x, train=False)
+    with torch.no_grad():
+        _, _, wseg_ref = o(x, segs)
+    m = mireg.opticalFlowReg3d(precision="fp32", width_div=8)
+    m.load_state_dict(o.state_dict())
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        flows, warped, wseg = m(x.to(DEV), segs.to(DEV))
+    assert wseg.shape == (2, 1, 64, 64, 64) and set(wseg.unique().tolist()) <= {0.0, 1.0, 2.0, 3.0}
+    assert (wseg.cpu() != wseg_ref).float().mean().item() < 1e-3                # rint ties on interpolated labels only
+    dice = mireg.dice_batch(segs[:, 0:1].to(DEV), wseg)
+    for b in range(2):
+        assert abs(dice[b].item() - float(oops.dice_average(segs[b, 0], wseg_ref[b, 0]))) < 2e-3
