@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import DT_BF16, DT_F32, ConvDesc, Pack3dJob, PackJob, View, WoptJob, Workspace, _stream, assign_tiles, rup, upload_table
+from .engine import ConvDesc, Pack3dJob, PackJob, View, WoptJob, Workspace, _stream, assign_tiles, rup, upload_table
 from .ops import SLOTS
 
 SPEC = [(2, 16, 7, (2, 2, 1)), (16, 32, 5, (2, 2, 1)), (32, 64, 3, (2, 2, 2)), (64, 128, 3, (2, 2, 2)),

@@ -9,7 +9,7 @@ Host-side only (torch.save / numpy); nothing here touches the GPU.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 import torch
