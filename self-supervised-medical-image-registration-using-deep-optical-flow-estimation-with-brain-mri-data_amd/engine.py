@@ -397,13 +397,15 @@ class ConvLayer:
         for c in sorted(cands):
             apply(*c)
             _lib.call("mireg_conv_gemm", ctypes.byref(d), st)
-            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(3):
-                _lib.call("mireg_conv_gemm", ctypes.byref(d), st)
-            b_.record()
-            b_.synchronize()
-            t = a.elapsed_time(b_)
+            t = float("inf")
+            for _ in range(2):                              # best of two 3-launch timings: candidates are often within 2-3 %
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3):
+                    _lib.call("mireg_conv_gemm", ctypes.byref(d), st)
+                b_.record()
+                b_.synchronize()
+                t = min(t, a.elapsed_time(b_))
             if t < best_t:
                 best, best_t = c, t
         self.ws.tuned[key] = best
@@ -562,13 +564,16 @@ class ConvLayer:
         for sp in sorted(cands):
             d = self._wgrad_desc(x, dy, sp, tmp.data_ptr())
             _lib.call("mireg_conv_wgrad", ctypes.byref(d), st)
-            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(3):
-                _lib.call("mireg_conv_wgrad", ctypes.byref(d), st)
-            b_.record()
-            b_.synchronize()
-            t = a.elapsed_time(b_) / 3 + (sp * elems * 4 / 3.0e9 if sp > 1 else 0.0)     # ms; slabs re-read at ~3 TB/s
+            t = float("inf")
+            for _ in range(2):                              # best of two 3-launch timings
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3):
+                    _lib.call("mireg_conv_wgrad", ctypes.byref(d), st)
+                b_.record()
+                b_.synchronize()
+                t = min(t, a.elapsed_time(b_))
+            t = t / 3 + (sp * elems * 4 / 3.0e9 if sp > 1 else 0.0)                        # ms; slabs re-read at ~3 TB/s
             if t < best_t:
                 best, best_t = sp, t
         self._wgrad_tuned = True
