@@ -9,9 +9,11 @@
 // the concat buffers (no torch.cat copies, K5).  Operands are bf16 (v_mfma_f32_32x32x16_bf16) or
 // fp32 (v_mfma_f32_32x32x2_f32, exact fp32: the parity path); accumulation is always fp32.
 //
-// Tiling: 256 threads = 4 waves, block tile BM x BN x (64 bytes of K), wave tile of 32x32 MFMA
-// sub-tiles, LDS double buffer with register-staged prefetch (global -> VGPR -> LDS), rows padded
-// to 80 B so that ds_read_b128 fragment reads are bank-conflict free.
+// Tiling: 256 threads = 4 waves, block tile BM x BN x (64 bytes of K), wave tile of 32x32 MFMA sub-tiles; operand tiles
+// go L2 -> LDS by LDS-DMA (buffer_load ... lds) into a 3/4-stage ring of unpadded 64-byte rows whose 16-byte chunks are
+// XOR-swizzled on the source side and on the ds_read_b128 side (bank-conflict free); counted vmcnt, one raw s_barrier
+// per K-step.  Unit-stride gathers whose grid is 16/32/64 pixels wide take the halo-staged kernel of conv_halo.hip instead
+// (each input pixel staged once per channel chunk, not once per tap); this file keeps the strided and small-grid cases.
 #include "mireg_common.h"
 #include "../../include/mireg.h"
 #include <stdlib.h>
@@ -285,12 +287,8 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
       wait_vmcnt<2 * (A_PW + B_PW)>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-#ifndef MIREG_ABL_NOISSUE
       issue((it + STAGES - 1) % STAGES);
-#endif
-#ifndef MIREG_ABL_NOCOMPUTE
       compute(it % STAGES);
-#endif
     }
   } else {
     for (; it < steady; ++it) {
@@ -845,12 +843,8 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
     wait_vmcnt<(STAGES - 2) * 4>();                                // STAGES-2 younger tiles x 4 DMAs stay in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#ifndef MIREG_ABL_NOISSUE
     issue((it + STAGES - 1) % STAGES);
-#endif
-#ifndef MIREG_ABL_NOCOMPUTE
     compute(it % STAGES);
-#endif
   }
   for (; it < nk; ++it) {
     wait_vmcnt_dyn(min(STAGES - 2, nk - 1 - it) * 4);
@@ -960,10 +954,17 @@ bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
 
 }  // namespace
 
+extern "C" int mireg_conv_halo_try(const mireg_conv_desc* p, hipStream_t stream);   // conv_halo.hip
+
 extern "C" {
 
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream) {
   if (!desc_ok(desc, false)) return MIREG_ERR_ARG;
+  if (desc->algo != 1) {                                            // 0: halo-staged kernel when it applies, 2: require it
+    const int rc = mireg_conv_halo_try(desc, stream);
+    if (rc != -100) return rc;
+    if (desc->algo == 2) return MIREG_ERR_UNSUPPORTED;
+  }
   return desc->dtype == MIREG_DTYPE_BF16 ? launch_fwd<__bf16>(*desc, stream) : launch_fwd<float>(*desc, stream);
 }
 

@@ -50,7 +50,8 @@ class ConvDesc(ctypes.Structure):
                 ("n_cls", ctypes.c_int), ("cls", ConvCls * 4), ("slab_cls_stride", ctypes.c_long),
                 ("x_D", ctypes.c_int), ("taps_z", ctypes.c_int), ("mul_z", ctypes.c_int), ("off_z", ctypes.c_int),
                 ("step_z", ctypes.c_int), ("g_D", ctypes.c_int), ("y_D", ctypes.c_int), ("y_mul_z", ctypes.c_int),
-                ("y_off_z", ctypes.c_int), ("tile_n", ctypes.c_int), ("stages", ctypes.c_int), ("slab_ld", ctypes.c_long)]
+                ("y_off_z", ctypes.c_int), ("tile_n", ctypes.c_int), ("stages", ctypes.c_int), ("slab_ld", ctypes.c_long),
+                ("algo", ctypes.c_int), ("tile_m", ctypes.c_int)]
 
 
 class PackClass(ctypes.Structure):
@@ -207,7 +208,7 @@ class Workspace:
     def load_tuning(self, path: str) -> None:
         import json
         d = json.load(open(path))
-        self.tuned = {tuple(k): tuple(v) for k, v in d["sites"]}
+        self.tuned = {tuple(k): (tuple(v) if len(v) == 4 else (v[0], v[1], 1, 0)) for k, v in d["sites"]}
         self.tuned_wgrad = dict(d["wgrad"])
 
     def need_scratch(self, elems: int) -> None:
@@ -224,6 +225,8 @@ NUM_CU = 256
 
 FORCE_TILE_N = int(os.environ.get('MIREG_TILE_N', '0'))   # experiments only
 USE_STEM = True
+FORCE_ALGO = None      # tests only: (algo, tile_m[, tile_n]) for every mireg_conv_gemm launch
+USE_HALO = os.environ.get('MIREG_NO_HALO', '0') != '1'   # experiments / A-B runs only
 USE_THIN = True     # module switch (tests compare the thin kernels with the GEMM path)
 
 
@@ -359,14 +362,16 @@ class ConvLayer:
 
     # ---- launches -----------------------------------------------------------------------------
     def _finish(self, d: ConvDesc, M: int, N: int, K: int, allow_split: bool, ncls: int = 1, site: str = "") -> None:
-        """M = rows of the largest class, K = smallest class K (bounds the split)."""
+        """Launch shape of one contraction site: kernel (halo-staged / ring), tile and split-K.
+        M = rows of the largest class, K = smallest class K (bounds the split)."""
         bk = 32 if self.ws.code == DT_BF16 else 16
         nk = (K + bk - 1) // bk
         d.dtype = self.ws.code
 
-        def apply(bn: int, split: int) -> None:
+        def apply(bn: int, split: int, algo: int = 1, tm: int = 0) -> None:
             d.tile_n = bn if N > 64 else 0
-            d.split_k = split
+            d.split_k, d.algo, d.tile_m = split, algo, tm
+            d.slab = None
             if split > 1:
                 d.slab_cls_stride = split * M * N
                 self.ws.need_scratch(ncls * split * M * N)
@@ -378,20 +383,37 @@ class ConvLayer:
         if FORCE_TILE_N and N > 64:
             bn = FORCE_TILE_N
         key = (self.name, site, M, N, K, ncls)
+        if FORCE_ALGO is not None:                          # tests / A-B runs: (algo, tile_m[, tile_n]); raises if not applicable
+            apply(FORCE_ALGO[2] if len(FORCE_ALGO) > 2 else bn, 1 if FORCE_ALGO[0] == 2 else (_split_for(tiles_for(bn), nk) if allow_split else 1),
+                  FORCE_ALGO[0], FORCE_ALGO[1])
+            return
         if key in self.ws.tuned:
             apply(*self.ws.tuned[key])
             return
-        heur = (bn, _split_for(tiles_for(bn), nk) if allow_split else 1)
+        # halo-staged kernel (conv_halo.hip): unit-stride gathers on 16/32/64-wide grids
+        d.split_k, d.algo, d.tile_m = 1, 0, 0
+        htiles = (ctypes.c_long * 2)()
+        halo = USE_HALO and bool(_lib.lib().mireg_conv_halo_eligible(ctypes.byref(d), htiles))
+        if halo:
+            tn = (N + bn - 1) // bn
+            tm = 256 if (htiles[1] and htiles[1] * tn * ncls >= 224) else (128 if htiles[0] else 256)
+            heur = (bn, 1, 2, tm)
+        else:
+            heur = (bn, _split_for(tiles_for(bn), nk) if allow_split else 1, 1, 0)
         if not (self.ws.tuning and allow_split and site):
             apply(*heur)
             return
-        # measured choice: every (tile width, split) whose grid is neither starved nor absurdly oversubscribed
+        # measured choice: every (kernel, tile, split) whose grid is neither starved nor absurdly oversubscribed
         cands = {heur}
         for b in ((128, 64) if N > 64 else (bn,)):
             t = tiles_for(b)
             for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32):
                 if sp <= max(nk // 4, 1) and 96 <= t * sp <= 2304 and ncls * sp * M * N <= (1 << 26):
-                    cands.add((b, sp))
+                    cands.add((b, sp, 1, 0))
+            if halo:
+                for i, tm in enumerate((128, 256)):
+                    if htiles[i]:
+                        cands.add((b, 1, 2, tm))
         best, best_t = heur, float("inf")
         st = _stream()
         for c in sorted(cands):
@@ -409,7 +431,6 @@ class ConvLayer:
             if t < best_t:
                 best, best_t = c, t
         self.ws.tuned[key] = best
-        d.slab = None
         apply(*best)
 
     def run_fwd_form(self, x: View, y: Optional[View], *, y32: Optional[View] = None, slope: float = 1.0,
@@ -447,13 +468,15 @@ class ConvLayer:
         d.bias = self.bias.data_ptr() if (bias and self.bias is not None) else None
         d.slope, d.accumulate = slope, int(accumulate)
         self._finish(d, x.B * Ho * Wo, self.Co, self.Kf, True, site="fwd" + ("+acc" if accumulate else ""))
-        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Co, d.split_k, d.tile_n),
+        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Co, d.split_k, d.tile_n, d.algo, d.tile_m),
                         2.0 * x.B * Ho * Wo * self.Co * self.kh * self.kw * self.Ci,
                         f"{self.name}:fwd M={x.B * Ho * Wo} N={self.Co} K={self.Kf} split={d.split_k}")
 
     @staticmethod
-    def _family(N: int, split: int, tile_n: int = 0) -> str:
+    def _family(N: int, split: int, tile_n: int = 0, algo: int = 1, tile_m: int = 0) -> str:
         bn = tile_n or (128 if N > 64 else (64 if N > 32 else 32))
+        if algo == 2:
+            return f"conv_halo_kernel<{tile_m},{bn}>"
         return f"conv_gemm_kernel<128,{bn}>" + ("+splitk" if split > 1 else "")
 
     @staticmethod
@@ -509,7 +532,7 @@ class ConvLayer:
         Mmax = max(g.B * gh * gw for _, gh, gw in live)
         Kmin = min(c["K"] for c, _, _ in live)
         self._finish(d, Mmax, self.Ci, Kmin, True, len(live), site="dgrad" + ("+acc" if accumulate else ""))
-        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Ci, d.split_k, d.tile_n), flops,
+        PROFILER.launch("mireg_conv_gemm", d, self._family(self.Ci, d.split_k, d.tile_n, d.algo, d.tile_m), flops,
                         f"{self.name}:dgrad M={Mmax}x{len(live)} N={self.Ci} K={Kmin} split={d.split_k}")
 
     def plan_wgrad(self, x: View, dy: View) -> None:

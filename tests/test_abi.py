@@ -36,7 +36,7 @@ def test_ctypes_mirrors_match_the_c_struct_layouts(tmp_path):
     from mireg import engine as e
     if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
         pytest.skip("gcc or the HIP headers are not available")
-    checks = [("mireg_conv_desc", e.ConvDesc, ["x_ld", "w", "y32", "slab", "n_cls", "cls", "slab_cls_stride", "x_D", "tile_n", "stages", "slab_ld"]),
+    checks = [("mireg_conv_desc", e.ConvDesc, ["x_ld", "w", "y32", "slab", "n_cls", "cls", "slab_cls_stride", "x_D", "tile_n", "stages", "slab_ld", "algo", "tile_m"]),
               ("mireg_conv_cls", e.ConvCls, ["w", "w_bytes"]),
               ("mireg_pack_job", e.PackJob, ["Cpad", "ld", "cls", "nsplit", "dunit0"]),
               ("mireg_pack3d_job", e.Pack3dJob, ["dst", "Co", "sz", "px", "unit0"]),
