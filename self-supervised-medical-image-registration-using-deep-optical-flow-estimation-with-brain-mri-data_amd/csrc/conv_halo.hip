@@ -13,15 +13,17 @@
 //
 // Structure (one workgroup = 4 waves, 2 x 2 over a BM-pixel x BN-channel tile):
 //   * pixel tile = BM/16 segments of 16 consecutive pixels of one image row (full rows of a 16/32/64 wide grid);
-//   * A halo: double-buffered, (R+ty-1) rows x (W+tx-1) pixels x 64 B, filled by buffer_load ... lds one chunk ahead;
-//   * B (weights of one tap x chunk): BN rows x 64 B in a 3/4-stage ring, one stage per K-step;
-//   * one raw s_barrier per K-step, counted s_waitcnt vmcnt(N), N recomputed per step (halo DMAs are issued in bursts);
+//   * A halo: 3 buffers of (R+ty-1) rows x (W+tx-1) pixels x 64 B, filled by buffer_load ... lds two chunks ahead, one
+//     instruction per wave and K-step;
+//   * B (weights of one tap x chunk): BN rows x 64 B in a 4-5 stage ring, one stage per K-step;
+//   * taps unrolled at compile time (3x3, 3x2, 2x3, 2x2), one raw s_barrier per K-step, s_waitcnt vmcnt(immediate);
 //   * LDS rows are 64 B, 16-B chunks XOR-swizzled with (row >> 2) & 3 on the DMA source side and on the read side;
 //     the M rows of a 32-row MFMA block are assigned to pixels so that each hardware ds_read_b128 lane group
 //     ({0-3,12-15,20-27} / {4-11,16-19,28-31}) reads 16 CONSECUTIVE halo rows: conflict-free at any tap shift.
 #include "mireg_common.h"
 #include "../../include/mireg.h"
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace mireg;
 
@@ -62,42 +64,52 @@ typedef __attribute__((address_space(3))) void* lds_void_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // n is wave-uniform; waiting for fewer outstanding is always safe
+#define MIREG_VM_CASE(k) case k: wait_vmcnt<k>(); break;
   switch (n) {
-    case 0: wait_vmcnt<0>(); break;
-    case 1: wait_vmcnt<1>(); break;
-    case 2: wait_vmcnt<2>(); break;
-    case 3: wait_vmcnt<3>(); break;
-    case 4: wait_vmcnt<4>(); break;
-    case 5: wait_vmcnt<5>(); break;
-    case 6: wait_vmcnt<6>(); break;
-    case 7: wait_vmcnt<7>(); break;
-    case 8: wait_vmcnt<8>(); break;
-    case 9: wait_vmcnt<9>(); break;
-    case 10: wait_vmcnt<10>(); break;
-    case 11: wait_vmcnt<11>(); break;
-    default: wait_vmcnt<12>(); break;
+    MIREG_VM_CASE(0) MIREG_VM_CASE(1) MIREG_VM_CASE(2) MIREG_VM_CASE(3) MIREG_VM_CASE(4) MIREG_VM_CASE(5) MIREG_VM_CASE(6)
+    MIREG_VM_CASE(7) MIREG_VM_CASE(8) MIREG_VM_CASE(9) MIREG_VM_CASE(10) MIREG_VM_CASE(11) MIREG_VM_CASE(12) MIREG_VM_CASE(13)
+    MIREG_VM_CASE(14) MIREG_VM_CASE(15) MIREG_VM_CASE(16) MIREG_VM_CASE(17) MIREG_VM_CASE(18) MIREG_VM_CASE(19) MIREG_VM_CASE(20)
+    MIREG_VM_CASE(21) MIREG_VM_CASE(22) MIREG_VM_CASE(23) MIREG_VM_CASE(24)
+    default: wait_vmcnt<25>(); break;
   }
+#undef MIREG_VM_CASE
 }
 
-// halo capacity (16-row DMA instructions per buffer): BM=128 -> 17 (2x66+..=264 rows), BM=256 -> 25 (6x66=396 rows)
+// halo capacity (16-row DMA instructions per buffer): BM=128 -> 17 (4 x 66 = 264 rows), BM=256 -> 25 (6 x 66 = 396 rows)
 template <int BM> struct HaloCap { static constexpr int INSTR = BM == 128 ? 17 : 25; };
 
-template <typename T, int BM, int BN>
-__global__ void __launch_bounds__(256, 2)
-conv_halo_kernel(const mireg_conv_desc pd) {
+// LDS plan of one launch (host and kernel agree through these): three halo buffers (two chunks ahead), the weight ring,
+// one 1-KiB dump slot for the padding DMAs; the epilogue reuses the space
+struct HaloPlan { int na, ka, d, bytes; bool ok; };
+template <int BM, int BN> __host__ __device__ inline HaloPlan halo_plan(int R, int W, int ty, int tx) {
+  HaloPlan h;
+  const int taps = ty * tx;
+  h.na = ((R + ty - 1) * (W + tx - 1) + 15) >> 4;                  // DMA instructions (1 KiB) per halo buffer
+  h.ka = (h.na + 3) >> 2;                                           // K-steps over which a halo is issued (one instruction per wave and step)
+  h.d = taps >= 6 ? 4 : 3;                                          // weight stages in flight (ring of d + 1)
+  const int epi = 128 * BN * 4 + 128 * 8;
+  const int ring = 3 * h.na * 1024 + (h.d + 1) * BN * 64 + 1024;
+  h.bytes = ring > epi ? ring : epi;
+  // tap shapes with an unrolled loop; the halo of chunk c+2 (issued from step (c, 0) on) must be older than every weight stage
+  // waited for from step (c+2, 0) on, and must not run into the next chunk's issue window
+  const bool shape = (ty == 3 && tx == 3) || (ty == 3 && tx == 2) || (ty == 2 && tx == 3) || (ty == 2 && tx == 2);
+  h.ok = shape && h.ka <= taps && 2 * taps - h.ka >= h.d && h.bytes <= 160 * 1024;
+  return h;
+}
+
+extern __shared__ __attribute__((aligned(1024))) unsigned char halo_smem[];
+
+// one output tile, start to finish (the body of both kernels below)
+template <typename T, int BM, int BN, int TY, int TX>
+__device__ __forceinline__ void halo_tile(const mireg_conv_desc& pd) {
   constexpr int CPC = Cfg<T>::CPC, BK = Cfg<T>::BK;
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
   constexpr int S = BM / 16;                                       // 16-pixel segments per tile
-  constexpr int B_GROUPS = BN / 16, B_PW = B_GROUPS / 4;           // DMA instructions per stage / per wave
-  constexpr int BSTAGES = BM == 128 ? 4 : 3;
-  constexpr int D = BSTAGES - 1;                                   // K-steps of weights in flight
+  constexpr int B_GROUPS = BN / 16;                                // weight DMA instructions per K-step
+  constexpr int B_PW = B_GROUPS / 4;                               // per wave
   constexpr int B_STAGE_BYTES = BN * 64;
-  constexpr int A_INSTR = HaloCap<BM>::INSTR, A_BUF_BYTES = A_INSTR * 1024, A_PW = (A_INSTR + 3) / 4;
-  constexpr int RING_BYTES = 2 * A_BUF_BYTES + BSTAGES * B_STAGE_BYTES;
-  constexpr int EPI_BYTES = 128 * BN * 4 + 128 * 8;                // one 128-row pass of the epilogue
-  constexpr int SMEM_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
-  static_assert(TM >= 1 && TN >= 1 && B_PW >= 1 && A_PW <= 7, "bad tile");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+  static_assert(TM >= 1 && TN >= 1, "bad tile");
+  unsigned char* const smem = halo_smem;
 
   mireg_conv_desc p = pd;
   const int cls = blockIdx.y;
@@ -129,68 +141,68 @@ conv_halo_kernel(const mireg_conv_desc pd) {
   const int n0 = tile_n * BN;
 
   // ---- halo geometry: input rows iy_min .. iy_min+HR-1, pixels ix_min .. ix_min+HP-1 ------------------------------
-  const int ty_n = p.taps_y, tx_n = p.taps_x, taps = ty_n * tx_n;
+  constexpr int ty_n = TY, tx_n = TX;                              // every class of this launch has this tap shape (host-grouped)
   const int HR = R + ty_n - 1, HP = W + tx_n - 1;
   const int iy_min = y0 + p.off_y + (p.step_y < 0 ? -(ty_n - 1) : 0);
   const int ix_min = p.off_x + (p.step_x < 0 ? -(tx_n - 1) : 0);
-  const int halo_rows = HR * HP;
-  const int NA = (halo_rows + 15) >> 4;                            // DMA instructions per halo buffer (<= A_INSTR, host-checked)
+  const HaloPlan plan = halo_plan<BM, BN>(R, W, ty_n, tx_n);       // the launch's dynamic LDS was sized with the same call
+  const int NA = plan.na, KA = plan.ka;
+  const int A_BUF_BYTES = NA * 1024, B_BASE = 3 * A_BUF_BYTES;
   const int cpt = p.x_C / CPC;                                     // 16-byte chunks per pixel
   const int nchunks = (cpt + 3) >> 2;                              // 64-byte channel chunks
-  const int nsteps = nchunks * taps;
 
   constexpr unsigned kOOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
-  // DMA lane roles: lane L of an instruction covers LDS row L>>2, physical chunk L&3 = logical chunk ^ ((row>>2)&3)
+  // DMA schedule.  Two measured facts shape it (profiles/README.md, round 2): (1) a CU has ONE scalar unit shared by its
+  // eight resident waves, so every scalar instruction of the K loop costs all of them a cycle -- a loop with run-time tap
+  // bookkeeping and a computed vmcnt ran 4.6x the scalar instructions of the ring kernel and 1.4x its time at 0.6x its bytes;
+  // (2) the LDS-DMA path only overlaps with the MFMAs when every wave issues the same few instructions every step.
+  // So: taps are unrolled at compile time, every K-step every wave issues exactly BN/64 weight DMAs (stage s+D) and ONE
+  // halo-slot DMA -- instruction 4k+wave of the halo two chunks ahead during the first KA steps of a chunk, otherwise a
+  // padding DMA (all lanes out of range: no memory access, zeros into a dump slot) -- which makes every vmcnt an immediate.
+  // lane L of a DMA instruction covers LDS row L>>2, physical chunk L&3 = logical chunk ^ ((row>>2)&3)
   const int lrow = lane >> 2;
   const int kc = (lane & 3) ^ ((lane >> 4) & 3);
-  unsigned a_src[A_PW];                                            // byte offset of the halo pixel (channel 0) or OOB
-  int nA = 0;
-#pragma unroll
-  for (int c = 0; c < A_PW; ++c) {
-    const int q = wid + 4 * c;
+  const unsigned pixB = (unsigned)(p.x_ld * (long)sizeof(T));
+  const unsigned img_off = (unsigned)((long)img * p.x_H * p.x_W * p.x_ld * (long)sizeof(T)) + (unsigned)(kc * 16);
+  const float inv_hp = 1.0f / (float)HP;
+  unsigned char* const dump = smem + plan.bytes - 1024;            // padding DMAs land here (never read)
+  // Out-of-range handling is arithmetic (an offset with bit 31 set is beyond every buffer: the DMA writes zeros): per-lane
+  // booleans would live in SGPR pairs and turn into exec-mask branches around the DMA instruction.
+  const int lim = (cpt - kc + 3) >> 2;                             // first 64-byte chunk in which this lane's 16 bytes lie beyond x_C
+  // halo-slot DMA of this wave for step k of the issue window of `chunk` (buffer `buf`); valid = uniform "real piece"
+  auto issueA = [&](int chunk, int buf, int k, bool valid) {
+    const int q = 4 * k + wid;
+    const bool real = valid && q < NA;                              // wave-uniform
     const int l = q * 16 + lrow;
-    const int hy = l / HP, hx = l - hy * HP;
+    const int hy = (int)(((float)l + 0.5f) * inv_hp), hx = l - hy * HP;        // exact: l < 2^10, HP <= 68
     const int iy = iy_min + hy, ix = ix_min + hx;
-    const bool ok = q < NA && l < halo_rows && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
-    a_src[c] = ok ? (unsigned)((((long)img * p.x_H + iy) * p.x_W + ix) * p.x_ld * (long)sizeof(T)) + (unsigned)(kc * 16) : kOOB;
-    nA += q < NA ? 1 : 0;
-  }
-  nA = __builtin_amdgcn_readfirstlane(nA);
+    const unsigned bad = (unsigned)(iy | (p.x_H - 1 - iy) | ix | (p.x_W - 1 - ix) | (HR - 1 - hy) | (lim - 1 - chunk)) & kOOB;
+    const unsigned off = (img_off + (unsigned)(iy * p.x_W + ix) * pixB + (unsigned)(chunk * 64)) | bad | (real ? 0u : kOOB);
+    unsigned char* dst = real ? smem + buf * A_BUF_BYTES + q * 1024 : dump;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t)dst, 16, off, 0, 0, 0);
+  };
+  // weight rows: groups g = wid + 4c (rows beyond N carry bit 31 from the start)
   unsigned b_src[B_PW];
 #pragma unroll
   for (int c = 0; c < B_PW; ++c) {
     const int n = n0 + (wid + 4 * c) * 16 + lrow;
-    b_src[c] = n < p.N ? (unsigned)((long)n * p.w_ld * (long)sizeof(T)) + (unsigned)(kc * 16) : kOOB;
+    b_src[c] = (unsigned)((long)min(n, p.N - 1) * p.w_ld * (long)sizeof(T)) + (unsigned)(kc * 16);
+    b_src[c] |= (unsigned)(p.N - 1 - n) & kOOB;
   }
-
-  auto issueA = [&](int chunk) {
-    unsigned char* Ab = smem + (chunk & 1) * A_BUF_BYTES;
-    const bool cok = chunk * 4 + kc < cpt;
-    const unsigned cb = (unsigned)(chunk * 64);
+  const int xc_bytes = p.x_C * (int)sizeof(T);
+  // weights of K-step (chunk, tap) into ring stage `stage`: k = tap * x_C + chunk * BK
+  auto issueB = [&](int chunk, int tap_bytes, int stage) {           // tap_bytes = tap * x_C * sizeof(T); chunks past the end: zeros
+    unsigned char* Bs = smem + B_BASE + stage * B_STAGE_BYTES;
+    const unsigned kb = (unsigned)(tap_bytes + chunk * 64);
+    const unsigned bad = (unsigned)(lim - 1 - chunk) & kOOB;
 #pragma unroll
-    for (int c = 0; c < A_PW; ++c) {
-      if (wid + 4 * c < NA) {                                       // wave-uniform
-        const unsigned off = (cok && a_src[c] != kOOB) ? a_src[c] + cb : kOOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t)(Ab + (wid + 4 * c) * 1024), 16, off, 0, 0, 0);
-      }
-    }
-  };
-  // weights of K-step (chunk, tap): k = tap * x_C + chunk * BK
-  int i_chunk = 0, i_tap = 0, i_stage = 0;                           // next weight stage to issue
-  auto issueB = [&]() {
-    unsigned char* Bs = smem + 2 * A_BUF_BYTES + i_stage * B_STAGE_BYTES;
-    const bool cok = i_chunk * 4 + kc < cpt;
-    const unsigned kb = (unsigned)((i_tap * p.x_C + i_chunk * BK) * (int)sizeof(T));
-#pragma unroll
-    for (int c = 0; c < B_PW; ++c) {
-      const unsigned off = (cok && b_src[c] != kOOB) ? b_src[c] + kb : kOOB;
+    for (int c = 0; c < B_PW; ++c) {          // braces matter: hipcc 7.2 drops the kernel's host stub for a braceless builtin-call body here
+      const unsigned off = (b_src[c] + kb) | bad;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_t)(Bs + (wid + 4 * c) * 1024), 16, off, 0, 0, 0);
     }
-    if (++i_tap == taps) { i_tap = 0; ++i_chunk; }
-    if (++i_stage == BSTAGES) i_stage = 0;
   };
 
   // ---- fragment rows: lane r of a 32-row block -> (segment 2i+sel, pixel xi) so that hardware lane groups read 16
@@ -218,7 +230,7 @@ conv_halo_kernel(const mireg_conv_desc pd) {
 
   auto compute = [&](int abuf, int bstage, int shift) {
     const unsigned char* As = smem + abuf * A_BUF_BYTES;
-    const unsigned char* Bs = smem + 2 * A_BUF_BYTES + bstage * B_STAGE_BYTES;
+    const unsigned char* Bs = smem + B_BASE + bstage * B_STAGE_BYTES;
     int a_off[TM], a_swz[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) { const int row = a_row0[i] + shift; a_off[i] = row * 64; a_swz[i] = (row >> 2) & 3; }
@@ -255,31 +267,52 @@ conv_halo_kernel(const mireg_conv_desc pd) {
     }
   };
 
-  // ---- pipeline ---------------------------------------------------------------------------------------------------
-  issueA(0);
+  // ---- pipeline: everything per step is a compile-time constant or a running scalar cursor ---------------------------
+  {
+    constexpr int TAPS = TY * TX;
+    constexpr int D = TAPS >= 6 ? 4 : 3, BST = D + 1;               // == HaloPlan::d
+    // DMAs of a wave younger than the weight stage it waits for: the halo slot of step s-D, then [weights, slot] of steps
+    // s-D+1 .. s-1 -- the same at every step, because weight stages past the end are still issued (out of range: zeros)
+    constexpr int YOUNG = 1 + (D - 1) * (1 + B_PW);
+    // prologue: halos of chunks 0 and 1 (older than any wait), then stages 0..D-1 in the steady pattern [weights, slot]
+    for (int k = 0; k < KA; ++k) issueA(0, 0, k, true);
+    for (int k = 0; k < KA; ++k) issueA(1, 1, k, nchunks > 1);
+    int i_kb = 0, i_tap = 0, istage = 0;                             // issue cursor of the weight ring: byte offset along K, tap, stage
+    int i_chunk = 0;
+    auto issue_next_B = [&]() {
+      issueB(i_chunk, i_kb, istage);
+      i_kb += xc_bytes;
+      if (++i_tap == TAPS) { i_tap = 0; i_kb = 0; ++i_chunk; }
+      if (++istage == BST) istage = 0;
+    };
 #pragma unroll
-  for (int s = 0; s < D; ++s)
-    if (s < nsteps) issueB();
-  // DMA issue order per wave: A(0) B(0..D-1) | step s: [A(c+1) if t == 0] B(s+D).  B(s) has landed once at most
-  // nB * min(D-1, steps left) weight DMAs plus (if the chunk's halo burst was issued after it, i.e. 1 <= t <= D-1) nA halo
-  // DMAs are still outstanding; the halo of chunk c is older than B(c, 0) by construction.
-  int c = 0, ky = 0, kx = 0, t = 0, bstage = 0;
-  const int sy_sign = p.step_y < 0 ? -1 : 1, sx_sign = p.step_x < 0 ? -1 : 1;
-  const int sy0 = p.step_y < 0 ? ty_n - 1 : 0, sx0 = p.step_x < 0 ? tx_n - 1 : 0;
-  for (int s = 0; s < nsteps; ++s) {
-    const int leftB = min(D - 1, nsteps - 1 - s);
-    const bool more_chunks = c + 1 < nchunks;
-    const int extraA = (t >= 1 && t <= D - 1 && more_chunks) ? nA : 0;
-    wait_vmcnt_dyn(B_PW * leftB + extraA);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (t == 0 && more_chunks) issueA(c + 1);
-    if (s + D < nsteps) issueB();
-    const int shift = (sy0 + sy_sign * ky) * HP + (sx0 + sx_sign * kx);
-    compute(c & 1, bstage, shift);
-    if (++bstage == BSTAGES) bstage = 0;
-    ++t;
-    if (++kx == tx_n) { kx = 0; if (++ky == ty_n) { ky = 0; t = 0; ++c; } }
+    for (int s = 0; s < D; ++s) { issue_next_B(); issueA(0, 0, 0, false); }
+    int bstage = 0, abuf = 0, ibuf = 2;                             // read cursors; ibuf = buffer of the halo two chunks ahead
+    const int sx_sign = p.step_x < 0 ? -1 : 1;
+    const int shift0 = (p.step_y < 0 ? TY - 1 : 0) * HP + (p.step_x < 0 ? TX - 1 : 0);
+    const int d_ky = (p.step_y < 0 ? -HP : HP) - sx_sign * (TX - 1);  // row shift from the last tap of a row to the first of the next
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = c + 2 < nchunks;                            // a halo two chunks ahead exists
+      int shift = shift0;
+      // one K-step; t is a literal (a generic lambda here would keep hipcc from emitting the kernel's host handle)
+#define MIREG_HALO_STEP(t)                                                             \
+      if constexpr ((t) < TAPS) {                                                      \
+        wait_vmcnt<YOUNG>();                                                           \
+        __builtin_amdgcn_s_barrier();                                                  \
+        asm volatile("" ::: "memory");                                                 \
+        issue_next_B();                                                                \
+        issueA(c + 2, ibuf, (t), more && (t) < KA);                                    \
+        compute(abuf, bstage, shift);                                                  \
+        shift += ((t) % TX == TX - 1) ? d_ky : sx_sign;                                \
+        if (++bstage == BST) bstage = 0;                                               \
+      }
+      MIREG_HALO_STEP(0) MIREG_HALO_STEP(1) MIREG_HALO_STEP(2) MIREG_HALO_STEP(3) MIREG_HALO_STEP(4)
+      MIREG_HALO_STEP(5) MIREG_HALO_STEP(6) MIREG_HALO_STEP(7) MIREG_HALO_STEP(8)
+#undef MIREG_HALO_STEP
+      if (++abuf == 3) abuf = 0;
+      if (++ibuf == 3) ibuf = 0;
+    }
+    wait_vmcnt<0>();                                                 // padding / past-the-end DMAs still target the ring
   }
 
   // ---- epilogue: 128 virtual rows per pass -> LDS fp32 -> 16-byte coalesced row stores ------------------------------
@@ -364,16 +397,45 @@ conv_halo_kernel(const mireg_conv_desc pd) {
   }
 }
 
+// every class of the launch has the tap shape TY x TX
+template <typename T, int BM, int BN, int TY, int TX>
+__global__ void __launch_bounds__(256, BM == 128 ? 2 : 1)          // 256-pixel tiles: 128 accumulators + pipelined fragments per lane
+conv_halo_kernel(const mireg_conv_desc pd) {
+  halo_tile<T, BM, BN, TY, TX>(pd);
+}
+
+// classes of different tap shapes in one launch (backward-data of a 5x5 / stride-2 convolution: 3x3, 3x2, 2x3, 2x2): blockIdx.y
+// picks the class, its shape picks a separately compiled tile function -- inlining the four unrolled loops into one kernel
+// makes the compiler hoist all their invariants at once (60-160 spilled SGPRs measured)
+typedef const __attribute__((address_space(4))) mireg_conv_desc* kernarg_desc_t;   // the descriptor where the launch put it
+template <typename T, int BM, int BN, int TY, int TX>
+__device__ __noinline__ void halo_tile_call(kernarg_desc_t kp) {
+  // read in place (scalar loads from the kernarg segment): a by-value or by-reference descriptor would go through scratch
+  const mireg_conv_desc& pd = *(const mireg_conv_desc*)kp;
+  halo_tile<T, BM, BN, TY, TX>(pd);
+}
+
+template <typename T, int BM, int BN>
+__global__ void __launch_bounds__(256, BM == 128 ? 2 : 1)
+conv_halo_multi_kernel(const mireg_conv_desc pd) {
+  const int code = pd.cls[blockIdx.y].taps_y * 4 + pd.cls[blockIdx.y].taps_x;
+  kernarg_desc_t kp = (kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr();   // pd is the only argument
+  if (code == 15) halo_tile_call<T, BM, BN, 3, 3>(kp);
+  else if (code == 14) halo_tile_call<T, BM, BN, 3, 2>(kp);
+  else if (code == 11) halo_tile_call<T, BM, BN, 2, 3>(kp);
+  else halo_tile_call<T, BM, BN, 2, 2>(kp);
+}
+
 // geometry of one class: does the halo path apply, and with how many tiles at BM rows per tile?
-bool class_ok(int gH, int gW, int ty, int tx, int bm, long* tiles_m, int n_img) {
+bool class_ok(int gH, int gW, int ty, int tx, int bm, int bn, long* tiles_m, int n_img) {
   if (gW != 16 && gW != 32 && gW != 64) return false;
   const int S = bm / 16, spr = gW / 16;
   if (S % spr) return false;
   const int R = S / spr;
   if (R < 1 || gH % R) return false;
-  if (ty * tx < 4 || ty > 5 || tx > 5) return false;                 // >= 4 K-steps per chunk: the halo burst lands in time
-  const int cap = bm == 128 ? HaloCap<128>::INSTR : HaloCap<256>::INSTR;
-  if (((R + ty - 1) * (gW + tx - 1) + 15) / 16 > cap) return false;
+  const HaloPlan h = bm == 128 ? (bn == 128 ? halo_plan<128, 128>(R, gW, ty, tx) : halo_plan<128, 64>(R, gW, ty, tx))
+                               : (bn == 128 ? halo_plan<256, 128>(R, gW, ty, tx) : halo_plan<256, 64>(R, gW, ty, tx));
+  if (!h.ok) return false;
   *tiles_m = (long)n_img * (gH / R);
   return true;
 }
@@ -389,14 +451,15 @@ extern "C" int mireg_conv_halo_eligible(const mireg_conv_desc* p, long* tiles_ou
   if (p->N < 64) return 0;
   if (p->dtype != MIREG_DTYPE_BF16 && p->dtype != MIREG_DTYPE_F32) return 0;
   const int ncls = p->n_cls > 1 ? p->n_cls : 1;
+  const int bn = (p->tile_n == 64 || p->N <= 64) ? 64 : 128;
   for (int b = 0; b < 2; ++b) {
     const int bm = b ? 256 : 128;
     long worst = 0;
     bool ok = true;
     for (int c = 0; c < ncls && ok; ++c) {
       long tm = 0;
-      ok = ncls > 1 ? class_ok(p->cls[c].g_H, p->cls[c].g_W, p->cls[c].taps_y, p->cls[c].taps_x, bm, &tm, p->n_img)
-                    : class_ok(p->g_H, p->g_W, p->taps_y, p->taps_x, bm, &tm, p->n_img);
+      ok = ncls > 1 ? class_ok(p->cls[c].g_H, p->cls[c].g_W, p->cls[c].taps_y, p->cls[c].taps_x, bm, bn, &tm, p->n_img)
+                    : class_ok(p->g_H, p->g_W, p->taps_y, p->taps_x, bm, bn, &tm, p->n_img);
       worst = tm > worst ? tm : worst;
     }
     if (ok) tiles_out[b] = worst;
@@ -404,17 +467,56 @@ extern "C" int mireg_conv_halo_eligible(const mireg_conv_desc* p, long* tiles_ou
   return tiles_out[0] > 0 || tiles_out[1] > 0;
 }
 
+template <typename T, int BM, int BN, int TY, int TX>
+static int launch_halo_shape(const mireg_conv_desc& p, long tiles_m, int bytes, hipStream_t stream) {
+  static bool attr_set = false;                                      // per instantiation; > 64 KiB of dynamic LDS needs the opt-in
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<T, BM, BN, TY, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return MIREG_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(tiles_m * ((p.N + BN - 1) / BN)), p.n_cls > 1 ? p.n_cls : 1, 1);
+  hipLaunchKernelGGL((conv_halo_kernel<T, BM, BN, TY, TX>), grid, dim3(256), bytes, stream, p);
+  return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
+}
+
+template <typename T, int BM, int BN>
+static int launch_halo_k(const mireg_conv_desc& p, long tiles_m, hipStream_t stream) {
+  const int ncls = p.n_cls > 1 ? p.n_cls : 1;
+  int bytes = 0;                                                     // dynamic LDS: the largest plan over the classes
+  bool uniform = true;
+  const int ty0 = ncls > 1 ? p.cls[0].taps_y : p.taps_y, tx0 = ncls > 1 ? p.cls[0].taps_x : p.taps_x;
+  for (int c = 0; c < ncls; ++c) {
+    const int gW = ncls > 1 ? p.cls[c].g_W : p.g_W, ty = ncls > 1 ? p.cls[c].taps_y : p.taps_y, tx = ncls > 1 ? p.cls[c].taps_x : p.taps_x;
+    const HaloPlan h = halo_plan<BM, BN>((BM / 16) / (gW / 16), gW, ty, tx);
+    bytes = h.bytes > bytes ? h.bytes : bytes;
+    uniform = uniform && ty == ty0 && tx == tx0;
+  }
+  if (uniform) {
+    if (ty0 == 3 && tx0 == 3) return launch_halo_shape<T, BM, BN, 3, 3>(p, tiles_m, bytes, stream);
+    if (ty0 == 3 && tx0 == 2) return launch_halo_shape<T, BM, BN, 3, 2>(p, tiles_m, bytes, stream);
+    if (ty0 == 2 && tx0 == 3) return launch_halo_shape<T, BM, BN, 2, 3>(p, tiles_m, bytes, stream);
+    if (ty0 == 2 && tx0 == 2) return launch_halo_shape<T, BM, BN, 2, 2>(p, tiles_m, bytes, stream);
+    return MIREG_ERR_UNSUPPORTED;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_multi_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return MIREG_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(tiles_m * ((p.N + BN - 1) / BN)), ncls, 1);
+  hipLaunchKernelGGL((conv_halo_multi_kernel<T, BM, BN>), grid, dim3(256), bytes, stream, p);
+  return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
+}
+
 template <typename T>
 static int launch_halo_t(const mireg_conv_desc& p, int bm, long tiles_m, hipStream_t stream) {
-  const int ncls = p.n_cls > 1 ? p.n_cls : 1;
   const int bn = (p.tile_n == 64 || p.N <= 64) ? 64 : 128;
-  const unsigned gx = (unsigned)(tiles_m * ((p.N + bn - 1) / bn));
-  dim3 grid(gx, ncls, 1);
-  if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_halo_kernel<T, 128, 128>), grid, dim3(256), 0, stream, p);
-  else if (bm == 128) hipLaunchKernelGGL((conv_halo_kernel<T, 128, 64>), grid, dim3(256), 0, stream, p);
-  else if (bn == 128) hipLaunchKernelGGL((conv_halo_kernel<T, 256, 128>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv_halo_kernel<T, 256, 64>), grid, dim3(256), 0, stream, p);
-  return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
+  if (bm == 128 && bn == 128) return launch_halo_k<T, 128, 128>(p, tiles_m, stream);
+  if (bm == 128) return launch_halo_k<T, 128, 64>(p, tiles_m, stream);
+  if (bn == 128) return launch_halo_k<T, 256, 128>(p, tiles_m, stream);
+  return launch_halo_k<T, 256, 64>(p, tiles_m, stream);
 }
 
 // Called by mireg_conv_gemm (conv_gemm.hip): >= 0 -> launched (MIREG_OK / error), -100 -> not applicable.

@@ -157,6 +157,10 @@ class RegistrationTrainer:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self.sync_loss_stats = sync_loss_stats and self.world > 1
+        # Adam's gradient scale under data parallelism.  Per-rank losses are normalised by the LOCAL batch, so the summed
+        # all-reduce is divided by world.  With sync_loss_stats the loss coefficients already carry the GLOBAL batch
+        # (finalize / ofe_bwd_coef receive B_global): the summed all-reduce then IS the gradient of the concatenated batch.
+        self.grad_scale = 1.0 if self.sync_loss_stats else 1.0 / self.world
         self.overlap = overlap
         self._graphs = None
         self._seg_ranges = [None]
@@ -212,7 +216,12 @@ class RegistrationTrainer:
             self._adam_tab, self._adam_n = upload_table([AdamJob(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                                                  self.flat_v.data_ptr(), self.flat_p.numel())], dev), 1
         self.x_static = torch.empty_like(x, memory_format=torch.contiguous_format)
+        # size-discovery forward: its BatchNorm running-statistics update is undone (the first real step does it once)
+        bufs = list(self.model.buffers())
+        saved = [b.detach().clone() for b in bufs]
         flows = self.eng.forward(self.x_static.copy_(x), True)
+        for b, v in zip(bufs, saved):
+            b.copy_(v)
         sizes = [tuple(f.shape[2:]) for f in flows]
         B, _, H, W = x.shape
         self.loss = FusedRegLoss(B, H, W, sizes, x.device, *self.loss_hyper)
@@ -373,7 +382,7 @@ class RegistrationTrainer:
             self._packs_fresh = True
             return
         _lib.call("mireg_adam_step", self._adam_tab.data_ptr(), self._adam_n, self.step_dev.data_ptr(), 1, self.lr, self.betas[0],
-                  self.betas[1], self.eps, 1.0 / self.world, st)
+                  self.betas[1], self.eps, self.grad_scale, st)
         if not self.packed:
             return
         if self._wopt_tab is None:
@@ -390,7 +399,7 @@ class RegistrationTrainer:
         tab, n, units, max_taps = self._wopt_tab
         nparam = sum(l.weight.numel() for l in self.eng.layers.values() if l.wgrad_slab is not None)
         PROFILER.call("adam_pack", 30.0 * nparam, "optimizer", "mireg_adam_pack", tab.data_ptr(), n, units, max_taps,
-                      self.step_dev.data_ptr(), 0, self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world,
+                      self.step_dev.data_ptr(), 0, self.lr, self.betas[0], self.betas[1], self.eps, self.grad_scale,
                       self.eng.ws.code, st, unit="B")
         self.eng.pack_weights(dgrad_only=True)
         self._packs_fresh = True
@@ -406,7 +415,7 @@ class RegistrationTrainer:
         def optimise(k: int) -> None:                      # on the optimizer stream, behind bucket k's all-reduce
             with torch.cuda.stream(self._opt_stream):
                 works[k].wait()
-                self._optim_phase(k, 1.0 / self.world)
+                self._optim_phase(k, self.grad_scale)
         for k, (run, rng) in enumerate(zip(runners, self._seg_ranges)):
             run()
             if self.world > 1:
@@ -503,7 +512,22 @@ class RegistrationTrainer:
                  "params": list(range(len(state)))}
         return {"state": state, "param_groups": [group]}
 
+    def set_hyper(self, lr: Optional[float] = None, betas=None, eps: Optional[float] = None) -> None:
+        """Change Adam's hyper-parameters.  They are by-value kernel arguments, i.e. frozen into captured hipGraphs, so the
+        graphs are dropped and re-captured on the next step (an lr schedule costs one capture per change)."""
+        new = (self.lr if lr is None else float(lr), self.betas if betas is None else (float(betas[0]), float(betas[1])),
+               self.eps if eps is None else float(eps))
+        if new != (self.lr, self.betas, self.eps):
+            self.lr, self.betas, self.eps = new
+            if self._graphs is not None:
+                torch.cuda.synchronize()
+            self._graphs, self._graph_opt, self._graph_fb = None, None, None
+
     def load_optimizer_state_dict(self, sd: dict) -> None:
+        groups = sd.get("param_groups") or []
+        if groups:                                          # reference resume: optim.load_state_dict restores these too (train.py:154)
+            g0 = groups[0]
+            self.set_hyper(g0.get("lr"), g0.get("betas"), g0.get("eps"))
         o = 0
         for i, p in enumerate(self.model.parameters()):
             n = p.numel()

@@ -186,9 +186,9 @@ def _dp_compare(name, size, port, tmp, strict=True):
             tr._fwd_bwd()
             acc = tr.flat_g.clone() if acc is None else acc + tr.flat_g
         tr.flat_g.copy_(acc)
-        tr.world = 2
+        tr.grad_scale = 0.5                                # the 1/world of the summed all-reduce
         tr._optim()
-        tr.world = 1
+        tr.grad_scale = 1.0
     if strict:
         diff = (tr.flat_p.cpu() - ret[0]).abs().max().item()
         assert diff < 5e-6, diff
@@ -199,6 +199,60 @@ def _dp_compare(name, size, port, tmp, strict=True):
         p0 = torch.cat([q.detach().reshape(-1) for q in m0.parameters()])
         da, db = (tr.flat_p.cpu() - p0).double(), (ret[0] - p0).double()
         assert torch.nn.functional.cosine_similarity(da, db, dim=0).item() > 0.9
+
+
+def _dp_sync_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mireg
+    from mireg.flownets import FlowNetS
+    from mireg.synth import make_pairs
+    torch.cuda.set_device(0)
+    model = mireg.opticalFlowReg("flownets", precision="fp32")
+    model.predictor = FlowNetS(batchNorm=False, precision="fp32")
+    nets.analytic_weights_(model)
+    model = model.to(DEV)
+    x, _ = make_pairs(4, 64, seed=3)
+    tr = mireg.RegistrationTrainer(model, use_graph=False, autotune=False, sync_loss_stats=True)
+    assert tr.world == 2 and tr.sync_loss_stats and tr.grad_scale == 1.0
+    losses = None
+    for _ in range(2):
+        losses = tr.step(x[rank * 2:(rank + 1) * 2].to(DEV)).tolist()
+    torch.cuda.synchronize()
+    torch.save((tr.flat_p.detach().cpu().clone(), losses), os.path.join(ret, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_sync_loss_stats_is_the_single_process_step_on_the_concatenated_batch():
+    """sync_loss_stats=True all-reduces the loss moments and normalises by the GLOBAL batch, so the summed gradient
+    all-reduce is already the concatenated-batch gradient: Adam must not divide by world again (a BatchNorm-free predictor
+    makes the two runs the same arithmetic; reference loss.py:55-62 whole-batch NCC)."""
+    import os, socket, tempfile
+    import torch.multiprocessing as mp
+    import mireg
+    from mireg.flownets import FlowNetS
+    from mireg.synth import make_pairs
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    tmp = tempfile.mkdtemp(prefix="mireg_dp_")
+    mp.spawn(_dp_sync_worker, args=(2, port, tmp), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp, f"rank{r}.pt")) for r in range(2))
+    assert torch.equal(r0[0], r1[0]) and r0[1] == r1[1]
+    model = mireg.opticalFlowReg("flownets", precision="fp32")
+    model.predictor = FlowNetS(batchNorm=False, precision="fp32")
+    nets.analytic_weights_(model)
+    model = model.to(DEV)
+    p0 = torch.cat([q.detach().reshape(-1).cpu() for q in model.parameters()])
+    x, _ = make_pairs(4, 64, seed=3)
+    tr = mireg.RegistrationTrainer(model, use_graph=False, autotune=False)
+    for _ in range(2):
+        losses = tr.step(x.to(DEV)).tolist()
+    assert all(abs(a - b) <= 1e-9 * abs(b) + 1e-12 for a, b in zip(r0[1], losses)), (r0[1], losses)
+    step = (tr.flat_p.cpu() - p0).abs().max().item()
+    diff = (tr.flat_p.cpu() - r0[0]).abs().max().item()
+    assert step > 1e-4 and diff < 5e-6, (step, diff)        # a double 1/world would leave diff ~ lr
 
 
 def test_fused_multiscale_tail_equals_per_scale_kernels():
