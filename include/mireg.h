@@ -242,7 +242,7 @@ typedef struct mireg_conv_desc {
   /* mireg_conv_wgrad: floats between consecutive Cout rows of the slab (0 = taps_y*taps_x*x_C); split-K slabs are
    * N*slab_ld apart */
   long slab_ld;
-  /* mireg_conv_gemm kernel choice.  algo 0 = the halo-staged kernel (conv_halo.hip) whenever mireg_conv_halo_eligible says
+  /* mireg_conv_gemm / mireg_conv_wgrad kernel choice.  algo 0 = the halo-staged kernel (conv_halo.hip) whenever mireg_conv_halo_eligible says
    * so, else the ring kernel; 1 = ring kernel; 2 = halo kernel or MIREG_ERR_UNSUPPORTED.  tile_m = pixels per halo tile
    * (0 = by tile count, 128 or 256 forces it). */
   int algo, tile_m;
@@ -250,6 +250,9 @@ typedef struct mireg_conv_desc {
 /* 1 when the halo-staged kernel applies to desc (unit-stride gather, grid 16/32/64 wide, >= 4 taps per class, N >= 64, no
  * split-K / y32 / depth); tiles_out[0] / [1] = pixel tiles per class at 128 / 256 pixels per tile (0 = not at that size). */
 int mireg_conv_halo_eligible(const mireg_conv_desc* desc, long* tiles_out);
+/* 1 when mireg_conv_wgrad takes the halo-staged backward-weights kernel (conv_wgrad_halo.hip) for desc: bf16, square kernel,
+ * stride 1 or 2 with every tap-parity class 3x3 / 3x2 / 2x3 / 2x2 (3x3 s1, 5x5 s2, 4x4 s2), dy grid 16 / 32 / 64 wide. */
+int mireg_conv_wgrad_halo_eligible(const mireg_conv_desc* desc);
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream);
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);
 

@@ -56,3 +56,31 @@ for name, form, cin, cout, k, s, H in SHAPES:
         t = sorted(res[tag])[len(res[tag]) // 2]
         line += f" {tag} {t:6.1f} us {fl/t/1e6:6.0f} TF |"
     print(line, flush=True)
+
+
+# ---- backward-weights: ring vs halo over a few splits -------------------------------------------------------------------
+WSHAPES = [("conv3_1", 256, 256, 3, 1, 32), ("conv4_1", 512, 512, 3, 1, 16), ("conv2", 64, 128, 5, 2, 128), ("conv3", 128, 256, 5, 2, 64),
+           ("deconv2", 64, 386, 4, 2, 64), ("deconv3", 128, 770, 4, 2, 32)]
+for name, cin, cout, k, s, H in WSHAPES:
+    w = torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5
+    lay = ConvLayer(name, w, None, s, (k - 1) // 2, 1, ws)
+    Ho = (H + 2 * ((k - 1) // 2) - k) // s + 1
+    x = ws.new(B, H, H, cin); x.buf.normal_()
+    y = ws.new(B, Ho, Ho, cout); y.buf.normal_()
+    fl = 2.0 * B * Ho * Ho * cout * cin * k * k
+    lay.plan_wgrad(x, y)
+    heur = lay.wgrad_split
+    line = f"{name:8s} wgrad {fl/1e9:6.1f} GF |"
+    for algo, tag, splits in ((1, "ring", (heur,)), (2, "halo", (2, 4, 8, 16, 24))):
+        engine.WGRAD_ALGO = algo
+        for sp in splits:
+            lay.wgrad_split = sp
+            lay.wgrad_slab = torch.zeros(sp, lay.Co, lay.Kf, device="cuda")
+            try:
+                lay.run_wgrad(x, y); torch.cuda.synchronize()
+            except RuntimeError:
+                continue
+            t = sorted(timed(lambda: lay.run_wgrad(x, y)) for _ in range(rounds))[rounds // 2]
+            line += f" {tag} z{sp} {t:6.1f} us {fl/t/1e6:5.0f} TF |"
+    engine.WGRAD_ALGO = 0
+    print(line, flush=True)

@@ -954,7 +954,8 @@ bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
 
 }  // namespace
 
-extern "C" int mireg_conv_halo_try(const mireg_conv_desc* p, hipStream_t stream);   // conv_halo.hip
+extern "C" int mireg_conv_halo_try(const mireg_conv_desc* p, hipStream_t stream);         // conv_halo.hip
+extern "C" int mireg_conv_wgrad_halo_try(const mireg_conv_desc* p, hipStream_t stream);   // conv_wgrad_halo.hip
 
 extern "C" {
 
@@ -970,6 +971,11 @@ int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream) {
 
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream) {
   if (!desc_ok(desc, true)) return MIREG_ERR_ARG;
+  if (desc->algo != 1) {                                            // 0: halo-staged kernel when it applies, 2: require it
+    const int rc = mireg_conv_wgrad_halo_try(desc, stream);
+    if (rc != -100) return rc;
+    if (desc->algo == 2) return MIREG_ERR_UNSUPPORTED;
+  }
   return desc->dtype == MIREG_DTYPE_BF16 ? launch_wgrad<__bf16>(*desc, stream) : launch_wgrad<float>(*desc, stream);
 }
 

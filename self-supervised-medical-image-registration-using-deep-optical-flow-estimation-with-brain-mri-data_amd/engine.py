@@ -225,6 +225,9 @@ NUM_CU = 256
 
 FORCE_TILE_N = int(os.environ.get('MIREG_TILE_N', '0'))   # experiments only
 USE_STEM = True
+WGRAD_SHARE_FLOOR = float(os.environ.get('MIREG_WGRAD_SHARE_FLOOR', '0.25'))   # tuner cost model (see _tune_wgrad)
+WGRAD_LATENCY_CAP = float(os.environ.get('MIREG_WGRAD_LATENCY_CAP', '2.5'))
+WGRAD_ALGO = int(os.environ.get('MIREG_WGRAD_ALGO', '0'))         # tests / A-B runs: 0 auto, 1 ring kernel, 2 halo kernel required
 FORCE_ALGO = None      # tests only: (algo, tile_m[, tile_n]) for every mireg_conv_gemm launch
 USE_HALO = os.environ.get('MIREG_NO_HALO', '0') != '1'   # experiments / A-B runs only
 USE_THIN = True     # module switch (tests compare the thin kernels with the GEMM path)
@@ -570,20 +573,32 @@ class ConvLayer:
         d.stages = self.ws.wgrad_stages
         d.slab = slab_ptr
         d.x_bytes, d.w_bytes = x.bytes_left, dy.bytes_left          # w_bytes carries the dy extent in WGRAD mode
+        d.algo = WGRAD_ALGO
         return d
 
     def _tune_wgrad(self, x: View, dy: View) -> None:
-        """Measured split-K of the backward-weights GEMM: kernel time + the cost of summing its slabs afterwards."""
+        """Measured split-K of the backward-weights GEMM.  The launch runs on the side stream next to the backward-data chain,
+        so what it costs the step is CHIP time, not latency: stand-alone time x the share of the chip's workgroup slots it
+        occupies (a launch of 128 workgroups leaves three quarters of the CUs to the main chain), plus the time to write and
+        re-read its fp32 slabs.  The share is floored (a 30-workgroup launch would otherwise always win and its latency would
+        stall the phase join) and the latency is capped."""
         bk = 32 if self.ws.code == DT_BF16 else 16
-        tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
-        nk = (dy.rows + bk - 1) // bk
         elems = self.Co * self.Kf
-        cands = {self.wgrad_split}
-        for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32, 44, 64, 96, 128, 192):
-            if sp <= max(nk // 8, 1) and 128 <= tiles * sp <= 2304 and sp * elems <= (1 << 26):
-                cands.add(sp)
+        nk = (dy.rows + bk - 1) // bk
+        probe = self._wgrad_desc(x, dy, 1, 0)
+        halo = probe.algo != 1 and bool(_lib.lib().mireg_conv_wgrad_halo_eligible(ctypes.byref(probe)))
+        if halo:
+            ncls = self.s * self.s
+            tiles, slots = ((self.Co + 127) // 128) * ((self.Cip + 31) // 32) * ncls, 512
+            cands = {sp for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if sp <= max(dy.rows // 512, 1) and tiles * sp <= 1536}
+        else:
+            tiles, slots = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128), 768
+            cands = {sp for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32, 44, 64, 96, 128, 192)
+                     if sp <= max(nk // 8, 1) and 128 <= tiles * sp <= 2304}
+        cands = {sp for sp in cands if sp * elems <= (1 << 26)} or {1}
         tmp = torch.empty(max(cands) * elems, device=self.ws.device, dtype=F32)
-        best, best_t, st = self.wgrad_split, float("inf"), _stream()
+        st = _stream()
+        res = {}
         for sp in sorted(cands):
             d = self._wgrad_desc(x, dy, sp, tmp.data_ptr())
             _lib.call("mireg_conv_wgrad", ctypes.byref(d), st)
@@ -596,9 +611,16 @@ class ConvLayer:
                 b_.record()
                 b_.synchronize()
                 t = min(t, a.elapsed_time(b_))
-            t = t / 3 + (sp * elems * 4 / 3.0e9 if sp > 1 else 0.0)                        # ms; slabs re-read at ~3 TB/s
-            if t < best_t:
-                best, best_t = sp, t
+            res[sp] = t / 3                                                                    # ms, stand-alone
+        t_min = min(res.values())
+        best, best_c = None, float("inf")
+        for sp, t in res.items():
+            if t > max(WGRAD_LATENCY_CAP * t_min, 0.08) and t > t_min:
+                continue
+            share = min(1.0, max(tiles * sp / slots, WGRAD_SHARE_FLOOR))
+            c = t * share + (2.0 * sp * elems * 4 / 3.5e9 if sp > 1 else 0.0)                  # slabs written + re-read at ~3.5 TB/s
+            if c < best_c:
+                best, best_c = sp, c
         self._wgrad_tuned = True
         self.ws.tuned_wgrad[self.name] = best
         if best != self.wgrad_split:
@@ -628,7 +650,8 @@ class ConvLayer:
         if self.ws.tuning and not getattr(self, "_wgrad_tuned", False):
             self._tune_wgrad(x, dy)
         d = self._wgrad_desc(x, dy, self.wgrad_split, self.wgrad_slab[slot * self.wgrad_split].data_ptr())
-        PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_kernel<128,128>",
+        halo = d.algo != 1 and bool(_lib.lib().mireg_conv_wgrad_halo_eligible(ctypes.byref(d)))
+        PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_halo_kernel" if halo else "conv_wgrad_kernel<128,128>",
                         2.0 * dy.rows * self.Co * self.kh * self.kw * self.Ci,
                         f"{self.name}:wgrad M={self.Co} N={self.Kf} K={dy.rows} split={d.split_k}")
 

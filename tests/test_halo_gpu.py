@@ -150,3 +150,49 @@ def test_halo_is_the_default_for_eligible_sites_and_refuses_others():
     assert _lib.lib().mireg_conv_halo_eligible(ctypes.byref(d), t) == 0
     d.g_W, d.taps_y, d.taps_x = 32, 1, 1               # 1x1: nothing to reuse
     assert _lib.lib().mireg_conv_halo_eligible(ctypes.byref(d), t) == 0
+
+
+WGRAD_CASES = [  # cin, cout, k, stride, pad, H (conv input), W, B, split
+    (256, 256, 3, 1, 1, 32, 32, 2, 1),     # conv3_1: one 3x3 class, 32-wide grid
+    (72, 136, 3, 1, 1, 16, 16, 3, 3),      # ragged channels both sides, 16-wide grid, split with an idle tail
+    (64, 128, 5, 2, 2, 64, 64, 2, 4),      # conv2-like: classes 3x3 / 3x2 / 2x3 / 2x2 over the parity sub-images, dy grid 32
+    (24, 40, 5, 2, 2, 128, 128, 1, 2),     # dy grid 64 wide (256-pixel chunks)
+    (96, 72, 4, 2, 1, 64, 64, 2, 5),       # 4x4 / stride 2 (the adjoint conv of the deconvolutions): four 2x2 classes
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_halo_backward_weights(case):
+    """conv_wgrad_halo.hip vs torch autograd on the bf16-rounded operands and vs the ring kernel it replaces."""
+    from mireg import engine
+    from mireg.engine import ConvLayer, Workspace, run_pack, run_unpack
+    cin, cout, k, s, p, H, W, B, split = case
+    ws = Workspace(torch.device(DEV), torch.bfloat16)
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).requires_grad_()
+    y = F.conv2d(x, w, None, s, p)
+    cot = torch.randn(y.shape, generator=g).bfloat16().float()
+    (y * cot).sum().backward()
+    lay = ConvLayer("t", w.detach().to(DEV), None, s, p, 1, ws)
+    run_pack(lay.pack_jobs(), ws.code, DEV)
+    xv, gv = _view_from(x.to(DEV), ws), _view_from(cot.to(DEV), ws)
+    got = {}
+    try:
+        for tag, algo in (("ring", 1), ("halo", 2)):
+            engine.WGRAD_ALGO = algo
+            lay.plan_wgrad(xv, gv)
+            lay.wgrad_split = split
+            lay.wgrad_slab = torch.full((split, lay.Co, lay.Kf), 7.0, device=DEV)      # stale contents must be overwritten
+            lay.wgrad_slab[:, :, :] = 7.0
+            for t in range(k * k):                                                        # pad channel slots are never written:
+                lay.wgrad_slab[:, :, t * lay.Cip + cin:(t + 1) * lay.Cip] = 0.0           # they are zero in a fresh slab
+            lay.grad_w = None
+            lay.run_wgrad(xv, gv)
+            run_unpack([lay.unpack_job()], DEV)
+            torch.cuda.synchronize()
+            got[tag] = lay.grad_w.detach().cpu().clone()
+            assert _rel(got[tag], w.grad) < 3e-2, tag
+    finally:
+        engine.WGRAD_ALGO = 0
+    assert _rel(got["halo"], got["ring"]) < 1e-3        # fp32 accumulation in a different order over <= 6k pixels
