@@ -178,7 +178,10 @@ def main():
                 "isolated": {"note": "same launches, single stream (nothing overlapping)",
                              "kernel_tflops": round(iso[dom[0]]["flops"] / (iso[dom[0]]["ms"] * 1e-3) / 1e12, 1),
                              "kernel_frac": round(iso[dom[0]]["flops"] / (iso[dom[0]]["ms"] * 1e-3) / 1e12 / peak, 4),
-                             "all_contractions_tflops": round(sum(v["flops"] for v in iso.values()) / (sum(v["ms"] for v in iso.values()) * 1e-3) / 1e12, 1)},
+                             "all_contractions_tflops": round(sum(v["flops"] for v in iso.values()) / (sum(v["ms"] for v in iso.values()) * 1e-3) / 1e12, 1),
+                             "ms_per_step": round(sum(v["ms"] for v in iso.values()) / 2, 3),
+                             "families": {k: {"ms_per_step": round(v["ms"] / 2, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                                          for k, v in iso.items()}},
                 "families": {k: {"launches_per_step": v["launches"] // 3, "ms_per_step": round(v["ms"] / 3, 3),
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in summ.items()},
                 # HBM-bound kernels of the step: algorithmic bytes / event-timed duration vs 8 TB/s

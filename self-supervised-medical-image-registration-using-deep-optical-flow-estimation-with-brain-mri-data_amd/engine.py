@@ -194,7 +194,7 @@ class Workspace:
         self.colsum_ws: Optional[torch.Tensor] = None      # row-segment partials of the bias-gradient column sums
         self.tuning = False
         self.tuned: Dict[tuple, Tuple[int, int]] = {}
-        self.tuned_wgrad: Dict[str, int] = {}              # layer name -> measured split-K of its backward-weights GEMM
+        self.tuned_wgrad: Dict[str, list] = {}             # layer name -> measured [split-K, algo] of its backward-weights GEMM
 
     def new(self, B: int, H: int, W: int, C: int, dtype: Optional[torch.dtype] = None, pad: int = 8) -> View:
         buf = torch.zeros(B, H, W, rup(C, pad), device=self.device, dtype=dtype or self.dtype)
@@ -225,8 +225,6 @@ NUM_CU = 256
 
 FORCE_TILE_N = int(os.environ.get('MIREG_TILE_N', '0'))   # experiments only
 USE_STEM = True
-WGRAD_SHARE_FLOOR = float(os.environ.get('MIREG_WGRAD_SHARE_FLOOR', '0.25'))   # tuner cost model (see _tune_wgrad)
-WGRAD_LATENCY_CAP = float(os.environ.get('MIREG_WGRAD_LATENCY_CAP', '2.5'))
 WGRAD_ALGO = int(os.environ.get('MIREG_WGRAD_ALGO', '0'))         # tests / A-B runs: 0 auto, 1 ring kernel, 2 halo kernel required
 FORCE_ALGO = None      # tests only: (algo, tile_m[, tile_n]) for every mireg_conv_gemm launch
 USE_HALO = os.environ.get('MIREG_NO_HALO', '0') != '1'   # experiments / A-B runs only
@@ -314,6 +312,7 @@ class ConvLayer:
                 self.classes.append(dict(py=py, px=px, ky0=ky0, kx0=kx0, nty=nty, ntx=ntx, cy=cy, cx=cx, K=K, pack=pack))
         self.wgrad_slab: Optional[torch.Tensor] = None
         self.wgrad_split = 1
+        self.wgrad_algo = 0                                 # mireg_conv_desc.algo of the backward-weights launch (0 auto, 1 ring, 2 halo)
         self.n_slots = 1
         self.grad_w: Optional[torch.Tensor] = None
         self.grad_b: Optional[torch.Tensor] = None
@@ -548,7 +547,9 @@ class ConvLayer:
         elif self.stem:
             self.wgrad_split = _lib.lib().mireg_stem_conv_blocks(x.B, x.H, x.W)
         elif self.name in self.ws.tuned_wgrad:
-            self.wgrad_split, self._wgrad_tuned = self.ws.tuned_wgrad[self.name], True
+            tw = self.ws.tuned_wgrad[self.name]
+            self.wgrad_split, self.wgrad_algo = (tw, 0) if isinstance(tw, int) else (tw[0], tw[1])
+            self._wgrad_tuned = True
         else:
             self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU) // tiles, max(nk // 8, 1), 192))   # <= 768 resident WGs
         if self.gpack is not None and self.n_slots * self.wgrad_split == 1:
@@ -560,7 +561,7 @@ class ConvLayer:
         if self.bias is not None and self.grad_b is None:
             self.grad_b = torch.zeros_like(self.bias, dtype=F32)
 
-    def _wgrad_desc(self, x: View, dy: View, split: int, slab_ptr: int) -> ConvDesc:
+    def _wgrad_desc(self, x: View, dy: View, split: int, slab_ptr: int, algo: Optional[int] = None) -> ConvDesc:
         d = ConvDesc()
         d.x, d.x_ld, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, x.H, x.W, self.Cip
         d.taps_y, d.taps_x = self.kh, self.kw
@@ -573,34 +574,34 @@ class ConvLayer:
         d.stages = self.ws.wgrad_stages
         d.slab = slab_ptr
         d.x_bytes, d.w_bytes = x.bytes_left, dy.bytes_left          # w_bytes carries the dy extent in WGRAD mode
-        d.algo = WGRAD_ALGO
+        d.algo = (WGRAD_ALGO or self.wgrad_algo) if algo is None else algo
         return d
 
     def _tune_wgrad(self, x: View, dy: View) -> None:
-        """Measured split-K of the backward-weights GEMM.  The launch runs on the side stream next to the backward-data chain,
-        so what it costs the step is CHIP time, not latency: stand-alone time x the share of the chip's workgroup slots it
-        occupies (a launch of 128 workgroups leaves three quarters of the CUs to the main chain), plus the time to write and
-        re-read its fp32 slabs.  The share is floored (a 30-workgroup launch would otherwise always win and its latency would
-        stall the phase join) and the latency is capped."""
+        """Measured (kernel, split-K) of the backward-weights GEMM: stand-alone time + the time to write and re-read its fp32
+        slabs.  (A chip-time model that favoured few-workgroup launches -- the launch shares the chip with the backward-data
+        chain -- was measured and lost 10-35 % of the step: the two streams do not fill each other's gaps, the step is the sum
+        of the kernels' stand-alone times, profiles/README.md round 2.)"""
         bk = 32 if self.ws.code == DT_BF16 else 16
         elems = self.Co * self.Kf
         nk = (dy.rows + bk - 1) // bk
         probe = self._wgrad_desc(x, dy, 1, 0)
-        halo = probe.algo != 1 and bool(_lib.lib().mireg_conv_wgrad_halo_eligible(ctypes.byref(probe)))
+        probe.algo = 0
+        halo = WGRAD_ALGO != 1 and bool(_lib.lib().mireg_conv_wgrad_halo_eligible(ctypes.byref(probe)))
+        cands = []
         if halo:
-            ncls = self.s * self.s
-            tiles, slots = ((self.Co + 127) // 128) * ((self.Cip + 31) // 32) * ncls, 512
-            cands = {sp for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if sp <= max(dy.rows // 512, 1) and tiles * sp <= 1536}
-        else:
-            tiles, slots = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128), 768
-            cands = {sp for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32, 44, 64, 96, 128, 192)
-                     if sp <= max(nk // 8, 1) and 128 <= tiles * sp <= 2304}
-        cands = {sp for sp in cands if sp * elems <= (1 << 26)} or {1}
-        tmp = torch.empty(max(cands) * elems, device=self.ws.device, dtype=F32)
+            tiles = ((self.Co + 127) // 128) * ((self.Cip + 31) // 32) * self.s * self.s
+            cands += [(sp, 2) for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if sp <= max(dy.rows // 512, 1) and 96 <= tiles * sp <= 1536]
+        if WGRAD_ALGO != 2:
+            tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
+            cands += [(sp, 1) for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32, 44, 64, 96, 128, 192)
+                      if sp <= max(nk // 8, 1) and 128 <= tiles * sp <= 2304]
+        cands = [c for c in cands if c[0] * elems <= (1 << 26)] or [(self.wgrad_split, self.wgrad_algo)]
+        tmp = torch.empty(max(c[0] for c in cands) * elems, device=self.ws.device, dtype=F32)
         st = _stream()
-        res = {}
-        for sp in sorted(cands):
-            d = self._wgrad_desc(x, dy, sp, tmp.data_ptr())
+        best, best_c = cands[0], float("inf")
+        for sp, algo in cands:
+            d = self._wgrad_desc(x, dy, sp, tmp.data_ptr(), algo)
             _lib.call("mireg_conv_wgrad", ctypes.byref(d), st)
             t = float("inf")
             for _ in range(2):                              # best of two 3-launch timings
@@ -611,24 +612,18 @@ class ConvLayer:
                 b_.record()
                 b_.synchronize()
                 t = min(t, a.elapsed_time(b_))
-            res[sp] = t / 3                                                                    # ms, stand-alone
-        t_min = min(res.values())
-        best, best_c = None, float("inf")
-        for sp, t in res.items():
-            if t > max(WGRAD_LATENCY_CAP * t_min, 0.08) and t > t_min:
-                continue
-            share = min(1.0, max(tiles * sp / slots, WGRAD_SHARE_FLOOR))
-            c = t * share + (2.0 * sp * elems * 4 / 3.5e9 if sp > 1 else 0.0)                  # slabs written + re-read at ~3.5 TB/s
+            c = t / 3 + (sp * elems * 4 / 3.0e9 if sp > 1 else 0.0)                            # ms; slabs re-read at ~3 TB/s
             if c < best_c:
-                best, best_c = sp, c
+                best, best_c = (sp, algo), c
         self._wgrad_tuned = True
-        self.ws.tuned_wgrad[self.name] = best
-        if best != self.wgrad_split:
-            self.wgrad_split = best
-            if self.gpack is not None and self.n_slots * best == 1:
+        self.ws.tuned_wgrad[self.name] = list(best)
+        self.wgrad_algo = best[1]
+        if best[0] != self.wgrad_split:
+            self.wgrad_split = best[0]
+            if self.gpack is not None and self.n_slots * best[0] == 1:
                 self.wgrad_slab = self.gpack.view(1, self.Co, self.Kf)
             else:
-                self.wgrad_slab = torch.zeros(self.n_slots * best, self.Co, self.Kf, device=self.ws.device, dtype=F32)
+                self.wgrad_slab = torch.zeros(self.n_slots * best[0], self.Co, self.Kf, device=self.ws.device, dtype=F32)
 
     def run_wgrad(self, x: View, dy: View, slot: int = 0) -> None:
         """x: tensor in this conv's INPUT space (C = Ci), dy: tensor in its OUTPUT space (C = Co).

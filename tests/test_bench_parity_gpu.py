@@ -1,0 +1,235 @@
+"""GPU parity AT THE SIZES bench.py measures (BASELINE.json configs[1]..[4]) against the CPU oracle.
+
+configs[1]  FlowNetS, 24 pairs of 256x256: one RegistrationTrainer.step, autotuned launch shapes + hipGraph replay, bf16
+            (the benchmarked configuration) and fp32 (parity mode): losses and all six flows of the first steps.
+configs[2]  FlowNetC, 24 pairs;  configs[3]  PWC-DC-Net, 48 pairs: eval-mode forward, fp32 and bf16.
+configs[4]  FlowNetS-3D at FULL width on a 128^3 volume pair: training-mode forward, OFEloss3d, a handful of parameter gradients.
+
+Tolerances.  fp32 (exact-fp32 MFMA): |flow error| <= 1e-4 * max(1, scale) + 4 * noise, noise = the oracle's own fp32 distance
+from its float64 run on the same batch (measured here, ~1e-5): north_star's "flow L2 vs reference < 1e-4".  bf16 operands:
+relative L2 per flow <= max(5e-2, 10 * eps_op), eps_op = the oracle's relative L2 move when only its weights and input are
+rounded to bf16 (the GPU also rounds every activation, ~14 layers deep); losses 1e-2 relative."""
+import pytest
+import torch
+
+from oracle import nets, ops as oops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def _engine_flows(tr):
+    e = tr.eng
+    return [e.flow0.nchw().float().cpu().clone()] + [e.flow32[l].nchw().float().cpu().clone() for l in (2, 3, 4, 5, 6)]
+
+
+def _oracle_steps(sd, x, n, dtype=torch.float32):
+    om = nets.OpticalFlowReg("flownets")
+    om.load_state_dict(sd)
+    om = om.to(dtype).train()
+    opt = torch.optim.Adam(om.parameters(), 1e-4, betas=(0.9, 0.999), eps=1e-4)
+    out = []
+    for _ in range(n):
+        flows, warped, _, _ = om(x.to(dtype))
+        vals = oops.ofe_loss(flows, warped, x[:, 0:1].to(dtype))
+        opt.zero_grad(); vals[3].backward(); opt.step()
+        out.append(([f.detach().clone() for f in flows], [float(v) for v in vals]))
+    return out
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_flownets_step_batch24_256_graph_autotune_vs_oracle(prec):
+    import mireg
+    from mireg.synth import make_pairs
+    torch.manual_seed(1)
+    model = mireg.opticalFlowReg("flownets", precision=prec)
+    nets.analytic_weights_(model)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x, _ = make_pairs(24, 256, seed=6)
+    ref = _oracle_steps(sd, x, 4)
+    tr = mireg.RegistrationTrainer(model.to(DEV), use_graph=True, autotune=True)
+    xd = x.to(DEV)
+    got = []
+    for _ in range(4):                                   # steps 1-2 eager with the tuned shapes, 3 captures, 4 replays the graph
+        losses = tr.step(xd).tolist()
+        got.append((_engine_flows(tr), losses))
+    assert tr._graphs is not None and len(tr.eng.ws.tuned) > 10
+    if prec == "fp32":
+        with torch.no_grad():                            # the oracle's own fp32 noise on this batch
+            o64 = nets.OpticalFlowReg("flownets"); o64.load_state_dict(sd); o64 = o64.double().train()
+            f64, _, _, _ = o64(x.double())
+        noise = [float((a.double() - b).abs().max()) for a, b in zip(ref[0][0], f64)]
+        for i, (a, b) in enumerate(zip(got[0][0], ref[0][0])):
+            err, scale = (a - b).abs().max().item(), b.abs().max().item()
+            assert err <= 1e-4 * max(1.0, scale) + 4 * noise[i], (i, err, scale, noise[i])
+        for a, b in zip(got[0][1], ref[0][1]):
+            assert abs(a - b) <= 2e-5 * abs(b) + 1e-7, (got[0][1], ref[0][1])
+        for k in (1, 2, 3):                              # later steps: Adam moves noise-level-gradient weights by +-lr
+            for a, b in zip(got[k][1], ref[k][1]):
+                assert abs(a - b) <= 5e-3 * abs(b) + 1e-6, (k, got[k][1], ref[k][1])
+        return
+    with torch.no_grad():                                # operand-rounding noise of the oracle
+        ob = nets.OpticalFlowReg("flownets")
+        ob.load_state_dict({k: (v.bfloat16().float() if v.dim() >= 3 else v) for k, v in sd.items()})
+        fb, _, _, _ = ob.train()(x.bfloat16().float())
+    for i, (a, b) in enumerate(zip(got[0][0], ref[0][0])):
+        eps_op = _rel_l2(fb[i], b)
+        assert _rel_l2(a, b) <= max(5e-2, 10 * eps_op), (i, _rel_l2(a, b), eps_op)
+    for k in range(4):
+        for a, b in zip(got[k][1], ref[k][1]):
+            assert abs(a - b) <= 1e-2 * abs(b) + 1e-6, (k, got[k][1], ref[k][1])
+    # graph replay, three Adam steps later: Adam moves every weight by ~lr per step whatever its gradient's size, so weights
+    # whose bf16 gradient is noise-level walk differently from the fp32 oracle's (the same happens between two fp32 summation
+    # orders, tests/test_trainer_gpu.py) -- the flows stay within a few times the single-step bound, the losses within 1e-2 (above)
+    for i, (a, b) in enumerate(zip(got[3][0], ref[3][0])):
+        assert _rel_l2(a, b) <= 0.5, (i, _rel_l2(a, b))
+
+
+@pytest.mark.parametrize("name,B", [("flownetc", 24), ("pwc", 48)])
+def test_flownetc_batch24_and_pwc_batch48_eval_forward_vs_oracle(name, B):
+    import mireg
+    x = nets.analytic_input((B, 2, 256, 256), seed=21)
+    om = nets.OpticalFlowReg(name)
+    nets.analytic_weights_(om)
+    om.eval()
+    with torch.no_grad():
+        fref, wref, _, _ = om(x)
+    for prec in ("fp32", "bf16"):
+        m = mireg.opticalFlowReg(name, precision=prec)
+        m.load_state_dict(om.state_dict())
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            flows, warped, _, _ = m(x.to(DEV))
+        assert len(flows) == len(fref)
+        for i, (a, b) in enumerate(zip(flows, fref)):
+            if prec == "fp32":
+                err, scale = (a.cpu() - b).abs().max().item(), b.abs().max().item()
+                assert err <= 5e-4 * max(1.0, scale), (name, i, err, scale)
+            else:
+                assert _rel_l2(a, b) <= 8e-2, (name, i, _rel_l2(a, b))
+        if prec == "fp32":
+            for a, b in zip(warped, wref):
+                assert (a.cpu() - b).abs().max().item() <= 1e-3
+        del m
+        torch.cuda.empty_cache()
+
+
+def test_flownets3d_full_width_128cubed_vs_oracle():
+    """BASELINE configs[4] at its real width (64..1024 channels) on one 128^3 pair, fp32: training-mode forward (batch statistics),
+    OFEloss3d and parameter gradients at the top, the middle and the bottom of the network against torch autograd on the CPU."""
+    import mireg
+    x = nets.analytic_input((1, 2, 128, 128, 128), seed=31)
+    o = nets.OpticalFlowReg3d(1)
+    nets.analytic_weights_(o)
+    sd = {k: v.detach().clone() for k, v in o.state_dict().items()}
+    o.train()
+    flows_ref, warped_ref = o(x)
+    vals_ref = oops.ofe_loss_3d(flows_ref, warped_ref, x[:, 0:1])
+    vals_ref[3].backward()
+    ref = {k: p.grad.detach().clone() for k, p in o.named_parameters()}
+    m = mireg.opticalFlowReg3d(precision="fp32")
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    xd = x.to(DEV)
+    flows, warped = m(xd)
+    vals = mireg.OFEloss3d(flows, warped, xd[:, 0:1])
+    vals[3].backward()
+    assert [tuple(f.shape) for f in flows] == [tuple(f.shape) for f in flows_ref]
+    for i, (a, b) in enumerate(zip(flows, flows_ref)):
+        err, scale = (a.detach().cpu() - b.detach()).abs().max().item(), b.detach().abs().max().item()
+        assert err <= 2e-3 * max(1.0, scale), (i, err, scale)       # BatchNorm3d over one sample's voxels, 10 layers deep
+    for a, b in zip(vals, vals_ref):
+        assert abs(a.item() - b.item()) <= 2e-3 * abs(b.item()) + 1e-6
+    P = dict(m.named_parameters())
+    names = [k for k in ref if k.endswith("weight") and ref[k].dim() == 5]
+    picks = [names[0], names[len(names) // 3], names[len(names) // 2], names[-4], names[-1]]
+    for k in picks:
+        a, b = P[k].grad.double().flatten().cpu(), ref[k].double().flatten()
+        cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)).item()
+        assert cos > 0.99, (k, cos)              # the deepest layers see 2^3 .. 4^3 voxels of one sample behind BatchNorm3d
+        assert abs(a.norm().item() / b.norm().item() - 1.0) < 2e-2, (k, a.norm().item(), b.norm().item())
+
+
+def test_model_forward_with_segs_is_the_reference_4_tuple():
+    """models.py:270-289: model(x, segs) -> (flows, warped, rounded warped segmentation in {0..3}, warped deformation grid), and
+    models.py:195-204 generate_grid / utils.py:15-23 grid_generator, against the oracle."""
+    import mireg
+    from mireg.synth import make_pairs
+    x, segs = make_pairs(3, 256, seed=8, magnitude=(0.5, 1.0))
+    om = nets.OpticalFlowReg("flownets")
+    nets.analytic_weights_(om)
+    om.eval()
+    with torch.no_grad():
+        fref, wref, sref, gref = om(x, segs)
+    m = mireg.opticalFlowReg("flownets", precision="fp32")
+    m.load_state_dict(om.state_dict())
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        flows, warped, wseg, wgrid = m(x.to(DEV), segs.to(DEV))
+    assert len(flows) == 2 and len(warped) == 2 and wseg.shape == (3, 1, 256, 256) and wgrid.shape == (3, 1, 256, 256)
+    for a, b in zip(flows, fref):
+        assert (a.cpu() - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+    for a, b in zip(warped, wref):
+        assert (a.cpu() - b).abs().max().item() <= 2e-4
+    assert (wgrid.cpu() - gref).abs().max().item() <= 2e-3                      # lines are 0/1 steps: a 1e-4 flow error moves them by 1e-4 px
+    assert wseg.dtype == torch.float32 and set(wseg.unique().cpu().tolist()) <= {0.0, 1.0, 2.0, 3.0}
+    assert (wseg.cpu() != sref).float().mean().item() < 2e-4                    # rint() flips only where the bilinear value sits on .5
+    g = mireg.generate_grid(2, 5, 7, torch.device(DEV))
+    assert torch.equal(g.cpu(), oops.generate_grid(2, 5, 7))
+    assert torch.equal(mireg.grid_generator(torch.device(DEV)).cpu(), oops.grid_generator())
+
+
+def test_reference_layout_checkpoint_resumes_on_the_gpu(tmp_path):
+    """train.py:150-156,183-188 / inference.py:147-148: a training_state.pt written the way the reference writes it (torch module
+    + torch.optim.Adam on the CPU oracle, whose state_dict keys are the reference's) loads into the HIP model, reproduces the
+    oracle's flows, and the trainer resumes from its Adam moments: the next step equals the oracle's next step."""
+    import mireg
+    from mireg import checkpoint
+    from mireg.synth import make_pairs
+    x, _ = make_pairs(4, 128, seed=5)
+    om = nets.OpticalFlowReg("flownets")
+    nets.analytic_weights_(om)
+    om.train()
+    opt = torch.optim.Adam(om.parameters(), 2e-4, betas=(0.9, 0.999), eps=1e-4)
+    for _ in range(2):
+        flows, warped, _, _ = om(x)
+        loss = oops.ofe_loss(flows, warped, x[:, 0:1])[3]
+        opt.zero_grad(); loss.backward(); opt.step()
+    path = str(tmp_path / "training_state.pt")
+    torch.save({"epoch": 7, "model_state_dict": om.state_dict(), "best_loss": 123.5, "optimizer_state_dict": opt.state_dict()}, path)
+    # the oracle continues for one more step
+    flows, warped, _, _ = om(x)
+    vals_ref = oops.ofe_loss(flows, warped, x[:, 0:1])
+    flows_ref = [f.detach().clone() for f in flows]
+    p_before = torch.cat([p.detach().reshape(-1).clone() for p in om.parameters()])
+    opt.zero_grad(); vals_ref[3].backward(); opt.step()
+    delta_ref = torch.cat([p.detach().reshape(-1) for p in om.parameters()]) - p_before
+    # HIP side
+    m = mireg.opticalFlowReg("flownets", precision="fp32").to(DEV)
+    tr = mireg.RegistrationTrainer(m, lr=1e-4, eps=1e-4, use_graph=False, autotune=False)
+    epoch, best = checkpoint.load_training_state(path, m, trainer=tr)
+    assert (epoch, best) == (8, 123.5) and tr.lr == 2e-4                          # optimizer hyper-parameters come from the file
+    assert int(tr.step_dev.item()) == 2
+    p0 = tr.flat_p.detach().cpu().clone()
+    assert (p0 - p_before).abs().max().item() == 0.0
+    losses = tr.step(x.to(DEV)).tolist()
+    for a, b in zip(losses, vals_ref):
+        assert abs(a - float(b)) <= 2e-4 * abs(float(b)) + 1e-6, (losses, [float(v) for v in vals_ref])
+    for a, b in zip(_engine_flows(tr), flows_ref):
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+    delta = tr.flat_p.detach().cpu() - p0
+    cos = torch.nn.functional.cosine_similarity(delta.double(), delta_ref.double(), dim=0).item()
+    assert cos > 0.98, cos                                                         # third Adam step continues the oracle's trajectory
+    assert abs(delta.abs().mean().item() / delta_ref.abs().mean().item() - 1.0) < 0.05
+    # and the file the trainer writes back has the reference's layout
+    out = str(tmp_path / "out.pt")
+    checkpoint.save_training_state(out, m, tr.optimizer_state_dict(), epoch, best)
+    ck = torch.load(out, weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "best_loss", "optimizer_state_dict"}
+    assert list(ck["model_state_dict"].keys()) == list(om.state_dict().keys())
+    assert ck["optimizer_state_dict"]["param_groups"][0]["lr"] == 2e-4
