@@ -304,6 +304,14 @@ int mireg_thin_conv_dgrad(const void* dy, long ld_dy, const void* w, long ld_w, 
 int mireg_thin_conv_wgrad_tiles(int B, int H, int W, int Cpad, int dtype, int* pixels_per_lane);
 int mireg_thin_conv_wgrad(const void* x, long ld_x, const void* dy, long ld_dy, float* slab, int ntiles, int B, int H,
                           int W, int Cpad, int dtype, hipStream_t stream);
+/* GEMM formulation of the same heads at the fine levels (the host runs it for >= 16k pixels): the FWD pack [2][9*Cpad] is
+ * [18][Cpad] row-major, so z[p][co*9+tap] = x[p] . w[co][tap] is a 1x1 mireg_conv_gemm to 18 columns that reads x once;
+ * mireg_thin_shift_sum: y[p][co] = bias[co] + sum_tap z[p + tap - (1,1)][co*9+tap]  (z fp32 [B*H*W][ld_z >= 18]);
+ * mireg_thin_gather18:  dz[q][co*9+tap] = dy[q - tap + (1,1)][co] (zero outside), the dy operand of a 1x1 mireg_conv_wgrad
+ * whose slab [z][18][Cpad] is the heads' standard slab [z][2][9*Cpad]. */
+int mireg_thin_shift_sum(const float* z, long ld_z, const float* bias, void* y, long ld_y, float* y32, long ld_y32, int B, int H,
+                         int W, int dtype, hipStream_t stream);
+int mireg_thin_gather18(const void* dy, long ld_dy, void* dz, long ld_dz, int B, int H, int W, int dtype, hipStream_t stream);
 
 /* ---- 7x7 / stride 2 / pad 3 input convolutions with 1 or 2 input channels and 64 outputs, bf16 (FlowNetS conv1
  * `FlowNetS/FlowNetS.py:18`, FlowNetC's siamese conv1 `flownet2/networks/FlowNetC.py:20`): K re-ordered to (ky, kx, ci)

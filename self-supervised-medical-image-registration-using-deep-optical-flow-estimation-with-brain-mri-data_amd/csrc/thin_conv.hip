@@ -315,6 +315,50 @@ inline bool thin_ok(const void* x, long ld_x, const void* w, long ld_w, int B, i
 
 }  // namespace
 
+// ---- GEMM formulation of the heads at the fine levels (>= 16k pixels): z[p][co*9 + tap] = sum_c x[p][c] * w[co][tap][c] is a 1x1
+// convolution to 18 columns (the FWD pack [2][9*Cpad] IS [18][Cpad] row-major) that reads x once instead of nine times, and
+// y[p][co] = bias + sum_tap z[p + tap][co*9 + tap] a 9-tap shift-sum over 72 B per pixel; backward-weights gathers
+// dz[q][co*9 + tap] = dy[q - tap][co] and runs the ring backward-weights GEMM on (dz, x).  The GEMMs are mireg_conv_gemm /
+// mireg_conv_wgrad; these two kernels are the pixel-wise ends.
+template <typename T>
+__global__ void __launch_bounds__(256)
+thin_shift_sum_kernel(const float* __restrict__ z, long ld_z, const float* __restrict__ bias, T* __restrict__ y, long ld_y,
+                      float* __restrict__ y32, long ld_y32, int B, int H, int W) {
+  const long n = (long)B * H * W * 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i & 1);
+    const long p = i >> 1;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H);
+    float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = yy + ky - 1, ix = xx + kx - 1;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+          acc += z[(p + (long)(ky - 1) * W + (kx - 1)) * ld_z + co * 9 + ky * 3 + kx];
+      }
+    if (y) y[p * ld_y + co] = (T)acc;
+    if (y32) y32[p * ld_y32 + co] = acc;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+thin_gather18_kernel(const T* __restrict__ dy, long ld_dy, T* __restrict__ dz, long ld_dz, int B, int H, int W) {
+  const long n = (long)B * H * W * 18;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 18);
+    const long q = i / 18;
+    const int co = c / 9, tap = c - co * 9, ky = tap / 3, kx = tap - ky * 3;
+    const int xx = (int)(q % W), yy = (int)((q / W) % H);
+    const int sy = yy - (ky - 1), sx = xx - (kx - 1);                  // y[s] received z[q] through tap (ky, kx) when q = s + tap
+    T v = (T)0.f;
+    if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) v = dy[(q - (long)(ky - 1) * W - (kx - 1)) * ld_dy + co];
+    dz[q * ld_dz + c] = v;
+  }
+}
+
 extern "C" {
 
 int mireg_thin_conv_fwd(const void* x, long ld_x, const void* w, long ld_w, const float* bias, void* y, long ld_y,
@@ -383,6 +427,30 @@ int mireg_thin_conv_wgrad(const void* x, long ld_x, const void* dy, long ld_dy, 
   const dim3 grid(ntiles, (Cpad / V + 31) / 32);
   if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((thin_wgrad_kernel<__bf16>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((thin_wgrad_kernel<float>), grid, dim3(256), 0, stream, a);
+  MIREG_LAUNCH_RET();
+}
+
+
+int mireg_thin_shift_sum(const float* z, long ld_z, const float* bias, void* y, long ld_y, float* y32, long ld_y32, int B, int H,
+                         int W, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(z && ld_z >= 18 && (y || y32) && B > 0 && H > 0 && W > 0 && (dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32));
+  const long n = (long)B * H * W * 2;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((thin_shift_sum_kernel<__bf16>), dim3(grid), dim3(256), 0, stream, z, ld_z, bias, (__bf16*)y, ld_y, y32, ld_y32, B, H, W);
+  else
+    hipLaunchKernelGGL((thin_shift_sum_kernel<float>), dim3(grid), dim3(256), 0, stream, z, ld_z, bias, (float*)y, ld_y, y32, ld_y32, B, H, W);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_thin_gather18(const void* dy, long ld_dy, void* dz, long ld_dz, int B, int H, int W, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(dy && dz && ld_dy >= 2 && ld_dz >= 18 && B > 0 && H > 0 && W > 0 && (dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32));
+  const long n = (long)B * H * W * 18;
+  const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((thin_gather18_kernel<__bf16>), dim3(grid), dim3(256), 0, stream, (const __bf16*)dy, ld_dy, (__bf16*)dz, ld_dz, B, H, W);
+  else
+    hipLaunchKernelGGL((thin_gather18_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)dy, ld_dy, (float*)dz, ld_dz, B, H, W);
   MIREG_LAUNCH_RET();
 }
 

@@ -227,6 +227,7 @@ FORCE_TILE_N = int(os.environ.get('MIREG_TILE_N', '0'))   # experiments only
 USE_STEM = True
 WGRAD_ALGO = int(os.environ.get('MIREG_WGRAD_ALGO', '0'))         # tests / A-B runs: 0 auto, 1 ring kernel, 2 halo kernel required
 FORCE_ALGO = None      # tests only: (algo, tile_m[, tile_n]) for every mireg_conv_gemm launch
+THIN_GEMM_ROWS = int(os.environ.get('MIREG_THIN_GEMM_ROWS', '16384'))   # heads with at least this many pixels run as 1x1 GEMMs
 USE_HALO = os.environ.get('MIREG_NO_HALO', '0') != '1'   # experiments / A-B runs only
 USE_THIN = True     # module switch (tests compare the thin kernels with the GEMM path)
 
@@ -318,6 +319,7 @@ class ConvLayer:
         self.grad_b: Optional[torch.Tensor] = None
         # two-channel 3x3 heads (predict_flow): vector-ALU streaming kernels instead of a 2-column GEMM
         self.thin = USE_THIN and (self.Co, self.kh, self.kw, self.s, self.p, self.d) == (2, 3, 3, 1, 1, 1)
+        self.thin_gemm = False                             # decided in plan_wgrad (forward decides per call)
         # 1-2 channel 7x7/s2 input convolutions: patch-staged kernels with K = (ky, kx, ci) (stem_conv.hip)
         self.stem = (USE_STEM and ws.code == DT_BF16 and (self.kh, self.kw, self.s, self.p, self.d) == (7, 7, 2, 3, 1)
                      and self.Ci <= 2 and self.Co == 64)
@@ -449,6 +451,9 @@ class ConvLayer:
                           self.bias.data_ptr() if (bias and self.bias is not None) else None, slope, y.ptr, y.ld,
                           x.B, x.H, x.W, self.Ci, self.Co, _stream())
             return
+        if self.thin and slope == 1.0 and not accumulate and x.rows >= THIN_GEMM_ROWS:
+            self._thin_gemm_fwd(x, y, y32, bias)
+            return
         if self.thin and slope == 1.0 and not accumulate:
             PROFILER.call("thin_conv_fwd", 2.0 * x.B * Ho * Wo * 2 * 9 * self.Ci, f"{self.name}:thin-fwd",
                           "mireg_thin_conv_fwd", x.ptr, x.ld, self.packF.data_ptr(), self.Kf,
@@ -542,7 +547,10 @@ class ConvLayer:
         bk = 32 if self.ws.code == DT_BF16 else 16
         tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
         nk = (dy.rows + bk - 1) // bk
-        if self.thin:
+        self.thin_gemm = self.thin and dy.rows >= THIN_GEMM_ROWS
+        if self.thin_gemm:                                   # 1x1 backward-weights GEMM on (dz, x): 128-column tiles x pixel splits
+            self.wgrad_split = max(1, min(512 // ((self.Cip + 127) // 128), nk // 8, 192))
+        elif self.thin:
             self.wgrad_split = _lib.lib().mireg_thin_conv_wgrad_tiles(dy.B, dy.H, dy.W, self.Cip, self.ws.code, None)
         elif self.stem:
             self.wgrad_split = _lib.lib().mireg_stem_conv_blocks(x.B, x.H, x.W)
@@ -631,6 +639,9 @@ class ConvLayer:
         if self.wgrad_slab is None:
             self.plan_wgrad(x, dy)
         assert x.C <= self.Cip and x.c0 + self.Cip <= x.ld and dy.c0 + rup(self.Co, 8) <= dy.ld, self.name
+        if self.thin and self.thin_gemm:
+            self._thin_gemm_wgrad(x, dy, slot)
+            return
         if self.thin:
             PROFILER.call("thin_conv_wgrad", 2.0 * dy.rows * 2 * 9 * self.Ci, f"{self.name}:thin-wgrad",
                           "mireg_thin_conv_wgrad", x.ptr, x.ld, dy.ptr, dy.ld,
@@ -649,6 +660,41 @@ class ConvLayer:
         PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_halo_kernel" if halo else "conv_wgrad_kernel<128,128>",
                         2.0 * dy.rows * self.Co * self.kh * self.kw * self.Ci,
                         f"{self.name}:wgrad M={self.Co} N={self.Kf} K={dy.rows} split={d.split_k}")
+
+    # ---- two-channel heads as 1x1 GEMMs at the fine levels (csrc/thin_conv.hip, GEMM formulation) -----------------------
+    def _thin_gemm_fwd(self, x: View, y: Optional[View], y32: Optional[View], bias: bool) -> None:
+        if getattr(self, "_z18", None) is None or self._z18.shape[0] != x.rows:
+            self._z18 = torch.zeros(x.rows, 32, device=self.ws.device, dtype=F32)
+        d = ConvDesc()
+        d.x, d.x_ld, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, x.H, x.W, self.Cip
+        d.taps_y = d.taps_x = d.mul_y = d.mul_x = d.step_y = d.step_x = 1
+        d.g_H, d.g_W, d.n_img = x.H, x.W, x.B
+        d.w, d.w_ld, d.N = self.packF.data_ptr(), self.Cip, 18           # the FWD pack [2][9*Cip] read as [18][Cip]
+        d.x_bytes, d.w_bytes = x.bytes_left, self.packF.numel() * self.packF.element_size()
+        d.y32, d.y32_ld = self._z18.data_ptr(), 32
+        d.y_H, d.y_W, d.y_mul_y, d.y_mul_x = x.H, x.W, 1, 1
+        d.slope, d.dtype, d.split_k, d.algo = 1.0, self.ws.code, 1, 1
+        PROFILER.launch("mireg_conv_gemm", d, "thin_conv_fwd", 2.0 * x.rows * 2 * 9 * self.Ci, f"{self.name}:thin-gemm-fwd")
+        out = y if y is not None else y32
+        _lib.call("mireg_thin_shift_sum", self._z18.data_ptr(), 32, self.bias.data_ptr() if (bias and self.bias is not None) else None,
+                  y.ptr if y is not None else None, y.ld if y is not None else 0,
+                  y32.ptr if y32 is not None else None, y32.ld if y32 is not None else 0, out.B, out.H, out.W, self.ws.code, _stream())
+
+    def _thin_gemm_wgrad(self, x: View, dy: View, slot: int) -> None:
+        if getattr(self, "_dz18", None) is None or self._dz18.rows != dy.rows:
+            self._dz18 = self.ws.new(dy.B, dy.H, dy.W, 18, pad=32)
+        dz = self._dz18
+        _lib.call("mireg_thin_gather18", dy.ptr, dy.ld, dz.ptr, dz.ld, dy.B, dy.H, dy.W, self.ws.code, _stream())
+        d = ConvDesc()
+        d.x, d.x_ld, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, x.H, x.W, self.Cip
+        d.taps_y = d.taps_x = d.mul_y = d.mul_x = d.step_y = d.step_x = 1
+        d.g_H, d.g_W, d.n_img = dy.H, dy.W, dy.B
+        d.y, d.y_ld, d.N = dz.ptr, dz.ld, 18
+        d.split_k, d.dtype, d.stages, d.algo = self.wgrad_split, self.ws.code, self.ws.wgrad_stages, 1
+        d.slab = self.wgrad_slab[slot * self.wgrad_split].data_ptr()   # [split][18][Cip] == [split][2][9*Cip]
+        d.slab_ld = self.Cip
+        d.x_bytes, d.w_bytes = x.bytes_left, dz.bytes_left
+        PROFILER.launch("mireg_conv_wgrad", d, "thin_conv_wgrad", 2.0 * dy.rows * 2 * 9 * self.Ci, f"{self.name}:thin-gemm-wgrad")
 
     def run_bias_grad(self, dy: View, accumulate: bool = False) -> None:
         if self.bias is None:
