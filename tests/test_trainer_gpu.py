@@ -249,7 +249,7 @@ def test_dp2_sync_loss_stats_is_the_single_process_step_on_the_concatenated_batc
     tr = mireg.RegistrationTrainer(model, use_graph=False, autotune=False)
     for _ in range(2):
         losses = tr.step(x.to(DEV)).tolist()
-    assert all(abs(a - b) <= 1e-7 * abs(b) + 1e-12 for a, b in zip(r0[1], losses)), (r0[1], losses)   # f64 moments, different partition
+    assert all(abs(a - b) <= 1e-6 * abs(b) + 1e-12 for a, b in zip(r0[1], losses)), (r0[1], losses)   # other launch shapes at B=2 vs B=4, f64 moments over another partition
     step = (tr.flat_p.cpu() - p0).abs().max().item()
     diff = (tr.flat_p.cpu() - r0[0]).abs().max().item()
     assert step > 1e-4 and diff < 5e-6, (step, diff)        # a double 1/world would leave diff ~ lr
