@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-CONV_GFLOP_PER_PAIR_FWD = {"flownets": 10.114}     # SURVEY section 8d (hook-measured on the reference)
+CONV_GFLOP_PER_PAIR_FWD = {"flownets": 10.114, "flownetc": 14.510, "pwc": 24.018}     # SURVEY section 8d (hook-measured on the reference)
 
 
 def log(msg):
@@ -72,6 +72,54 @@ def cpu_baseline(B, size, steps, seed):
             "sample": f"{len(times)} train steps (after 1 warm-up) of the CPU oracle, FlowNetS B={B} {size}x{size} fp32, median"}
 
 
+def hbm_block(hbm):
+    """Algorithmic HBM bytes / event-timed launch duration against 8 TB/s for the HBM-bound kernels of a step."""
+    return {k: {"launches_per_step": v["launches"], "us_per_launch": round(v["ms"] * 1e3 / v["launches"], 1),
+                "MB_per_launch": round(v["flops"] / v["launches"] / 1e6, 2),
+                "GBps": round(v["flops"] / (v["ms"] * 1e-3) / 1e9, 1), "frac_of_8TBps": round(v["flops"] / (v["ms"] * 1e-3) / 8e12, 4)}
+            for k, v in hbm.items()}
+
+
+def model_leg(name, batch, precision, dev, steps=10, warm=4):
+    """A short train-step measurement of another predictor (BASELINE configs[2] / [3]) on this GPU: throughput from a timed hipGraph
+    region, then one eager step with per-launch events for the roofline blocks."""
+    import mireg
+    from mireg.engine import PROFILER
+    from mireg.synth import make_pairs
+    torch.manual_seed(6)
+    model = mireg.opticalFlowReg(name, precision=precision).to(dev)
+    tr = mireg.RegistrationTrainer(model, lr=1e-4, eps=1e-4, use_graph=True, autotune=True)
+    x = make_pairs(batch, 256, seed=6)[0].to(dev)
+    for _ in range(warm):
+        tr.step(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = tr.step(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tr.use_graph = False
+    PROFILER.enabled, PROFILER.records, PROFILER.byte_records = True, [], []
+    tr._fwd_bwd()
+    tr._optim()
+    summ, hbm = PROFILER.summary(), PROFILER.summary(bytes_=True)
+    PROFILER.enabled = False
+    fl = sum(v["flops"] for v in summ.values())
+    ms = sum(v["ms"] for v in summ.values())
+    dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    peak = PEAK_TFLOPS[precision]
+    out = {"pairs_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": batch, "loss_total": float(losses[3]),
+           "step_tflops": round(3 * CONV_GFLOP_PER_PAIR_FWD[name] * batch / dt / 1e3, 1),
+           "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12, 1), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12 / peak, 4), "traffic": None,
+                        "all_contractions": {"achieved": round(fl / (ms * 1e-3) / 1e12, 1), "gflop_per_step": round(fl / 1e9, 1),
+                                             "ms_per_step": round(ms, 3)}},
+           "hbm_roofline": hbm_block(hbm)}
+    del tr, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +132,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-3d", action="store_true", help="skip the 128^3 affmodel leg")
+    ap.add_argument("--no-other-models", action="store_true", help="skip the FlowNetC / PWC-DC-Net train-step legs")
     ap.add_argument("--tune-cache", default=None, help="JSON of measured launch shapes (written after tuning, reused when present)")
     ap.add_argument("--no-autotune", action="store_true", help="heuristic launch shapes (counter-collection runs: the tuning pass is slow there)")
     ap.add_argument("--cpu-steps", type=int, default=20)
@@ -185,26 +234,31 @@ def main():
                 "families": {k: {"launches_per_step": v["launches"] // 3, "ms_per_step": round(v["ms"] / 3, 3),
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in summ.items()},
                 # HBM-bound kernels of the step: algorithmic bytes / event-timed duration vs 8 TB/s
-                "hbm_kernels": {k: {"launches_per_step": v["launches"] // 3, "us_per_launch": round(v["ms"] * 1e3 / v["launches"], 1),
-                                    "GBps": round(v["flops"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                    "frac_of_8TBps": round(v["flops"] / (v["ms"] * 1e-3) / 8e12, 4)} for k, v in hbm.items()}}
+                "hbm_kernels": {k: dict(v, launches_per_step=v["launches_per_step"] // 3) for k, v in hbm_block(hbm).items()}}
 
-        # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process, so the figure is
-        # the committed `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum` pass over this same command (eager launches,
-        # scratch/pmc_bench.sh), per launch, with the guide's gfx950 correction: wide (16 B/lane) reads are tallied at half
-        # their bytes -> 2 * RDREQ * 64 B + WRREQ * 64 B.  null when the summary is absent or the kernel differs.
+        # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process, so the figure comes from a
+        # committed `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum` pass over this same command (scratch/pmc_bench.sh), per
+        # launch, with the guide's gfx950 correction (wide reads are tallied at half their bytes: 2 * RDREQ * 64 B + WRREQ * 64 B).
+        # The summary records the git revision of csrc/ it was taken on; when the kernels have changed since, or the dominant
+        # kernel is not in it, traffic stays null rather than quoting a stale number.
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_conv_kernels.json")))
-            if dom[0].startswith("conv_wgrad") and args.model == "flownets" and args.batch == 24 and args.size == 256:
-                ent = next(v for k, v in pmc.items() if "conv_wgrad_dma_kernel" in k)
+            import subprocess
+            prof = os.path.join(ROOT, "profiles", "round2_pmc_conv_kernels.json")
+            pmc = json.load(open(prof))
+            csrc = os.path.join(ROOT, "self-supervised-medical-image-registration-using-deep-optical-flow-estimation-with-brain-mri-data_amd", "csrc")
+            import hashlib
+            hsh = hashlib.sha1(b"".join(open(os.path.join(csrc, f), "rb").read() for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h")))).hexdigest()[:12]
+            key = {"conv_wgrad_kernel<128,128>": "conv_wgrad_dma_kernel", "conv_wgrad_halo_kernel": "conv_wgrad_halo"}.get(dom[0], dom[0].split("<")[0])
+            ent = next((v for k, v in pmc["kernels"].items() if key in k), None)
+            if ent is not None and pmc.get("csrc_sha1") == hsh and args.model == "flownets" and args.batch == 24 and args.size == 256:
                 rd, wr = ent["TCC_EA0_RDREQ_sum"]["mean_per_launch"], ent["TCC_EA0_WRREQ_sum"]["mean_per_launch"]
                 roof["traffic"] = round(2 * rd * 64 + wr * 64)
-                roof["traffic_note"] = ("bytes per launch, mean over the backward-weights launches of the step, from "
-                                        "profiles/round1_pmc_conv_kernels.json (separate rocprofv3 --pmc pass); algorithmic "
-                                        "bytes per launch (x + dy once, dW once): 23.4 MB -> operand re-reads across output "
-                                        "tiles and split-K slab writes dominate")
+                roof["traffic_note"] = f"bytes per launch, mean over the step's launches of {key}, from profiles/round2_pmc_conv_kernels.json (csrc sha1 {hsh})"
+            else:
+                roof["traffic_note"] = (f"null: profiles/round2_pmc_conv_kernels.json was taken on csrc sha1 {pmc.get('csrc_sha1')}, "
+                                        f"this tree is {hsh}" if ent is not None else f"null: {key} not in the committed PMC summary")
         except Exception as e:                                       # noqa: BLE001 -- the bench line must still print
-            roof["traffic_note"] = f"PMC summary unavailable: {e!r}"
+            roof["traffic_note"] = f"null: PMC summary unavailable ({e!r})"
 
     # ---- quality leg: warped Dice of the (random-init, K-step-trained) model, GPU vs CPU oracle ---------------
     dice = None
@@ -338,7 +392,17 @@ def main():
                 opt_f.step()
                 return loss
             t3, l3 = timed(f3_train, 3, warm=1)
-            vol_line["flownets3d_train"] = {"volumes_per_s": round(8 / t3, 1), "ms_per_step": round(t3 * 1e3, 3), "loss": float(l3.detach()),
+            PROFILER.enabled, PROFILER.records, PROFILER.byte_records = True, [], []
+            f3_train()
+            s3 = PROFILER.summary()
+            PROFILER.enabled = False
+            fl3 = sum(v["flops"] for v in s3.values())
+            ms3 = sum(v["ms"] for v in s3.values())
+            roof3 = {"bound": "mfma", "kernel": "conv3d contractions (forward, backward-data, backward-weights)", "peak": PEAK_TFLOPS[args.precision],
+                     "unit": "TFLOP/s", "achieved": round(fl3 / (ms3 * 1e-3) / 1e12, 1), "frac": round(fl3 / (ms3 * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision], 4),
+                     "gflop_per_step": round(fl3 / 1e9, 1), "contraction_ms_per_step": round(ms3, 3),
+                     "step_tflops": round(fl3 / t3 / 1e12, 1), "traffic": None}
+            vol_line["flownets3d_train"] = {"roofline": roof3,"volumes_per_s": round(8 / t3, 1), "ms_per_step": round(t3 * 1e3, 3), "loss": float(l3.detach()),
                                             "batch": 8, "note": "configs[4]: FlowNetS over 128^3 volume pairs (Conv3d / BatchNorm3d / "
                                             "ConvTranspose3d, 3-channel flow), six-scale warp + OFEloss3d, HIP backward, Adam; eager, 1 GPU"}
             log(f"3-D FlowNetS train: {8 / t3:.2f} volumes/s ({t3 * 1e3:.1f} ms/step)")
@@ -373,6 +437,19 @@ def main():
         except Exception as e:
             vol_line = dict(vol_line or {}, error=repr(e))
 
+    # ---- BASELINE configs[2] / [3] on this GPU: FlowNetC (batch 24) and PWC-DC-Net (batch 48) train steps ----------------------
+    others = None
+    if rank == 0 and world == 1 and args.model == "flownets" and not args.no_other_models:
+        others = {}
+        del trainer, model
+        torch.cuda.empty_cache()
+        for nm, bsz in (("flownetc", 24), ("pwc", 48)):
+            try:
+                others[nm] = model_leg(nm, bsz, args.precision, dev)
+                log(f"{nm} batch {bsz}: {others[nm]['pairs_per_s']} pairs/s ({others[nm]['ms_per_step']} ms/step)")
+            except Exception as e:                                   # noqa: BLE001
+                others[nm] = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.batch, args.size, args.cpu_steps, seed=6)
@@ -386,7 +463,8 @@ def main():
                                       f"{args.precision} operands fp32 accumulate, train step", "global_batch": args.batch * world,
                           "parallelism": f"dp{world}", "hipgraph": not args.no_graph},
                "loss": {"photo": loss_vals[0], "corr": loss_vals[1], "smooth": loss_vals[2], "total": loss_vals[3]},
-               "roofline": roof, "cpu_baseline": cpu, "dice": dice, "eval": ev_line, "volumes3d": vol_line}
+               "roofline": roof, "cpu_baseline": cpu, "dice": dice, "eval": ev_line, "volumes3d": vol_line, "other_models": others,
+               "dist": {"world": world, "backend": (torch.distributed.get_backend() if world > 1 else None)}}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import ConvDesc, Pack3dJob, PackJob, View, WoptJob, Workspace, _stream, assign_tiles, rup, upload_table
+from .engine import PROFILER, ConvDesc, Pack3dJob, PackJob, View, WoptJob, Workspace, _stream, assign_tiles, rup, upload_table
 from .ops import SLOTS
 
 SPEC = [(2, 16, 7, (2, 2, 1)), (16, 32, 5, (2, 2, 1)), (32, 64, 3, (2, 2, 2)), (64, 128, 3, (2, 2, 2)),
@@ -131,7 +131,7 @@ class Conv3dLayer:
                 d.split_k, d.slab_cls_stride = split, split * M * N
                 self.ws.need_scratch(split * M * N)
                 d.slab = self.ws.get_scratch().data_ptr()
-        _lib.call("mireg_conv_gemm", ctypes.byref(d), _stream())
+        PROFILER.launch("mireg_conv_gemm", d, "conv3d_gemm", 2.0 * M * N * K, f"{getattr(self, 'name', 'conv3d')} M={M} N={N} K={K}")
 
     # ---- backward (autograd of nn.Conv3d, reference models.py:39-43 trained through loss.backward()) ----
     def dgrad_classes(self) -> list:
@@ -236,7 +236,7 @@ class Conv3dLayer:
             d.split_k, d.dtype, d.stages = split, self.ws.code, 3
             d.slab, d.slab_ld = self.slab.data_ptr() + 4 * tz * K2, self.Kf
             d.x_bytes, d.w_bytes = x.bytes_left, gy.bytes_left
-            _lib.call("mireg_conv_wgrad", ctypes.byref(d), _stream())
+            PROFILER.launch("mireg_conv_wgrad", d, "conv3d_wgrad", 2.0 * P * self.Co * K2, f"conv3d-wgrad tz={tz}")
 
     @staticmethod
     def unpack_grads(pairs, ws: Workspace):

@@ -11,22 +11,46 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import DT_BF16, DT_F32, View, _stream, rup
+from .engine import DT_BF16, DT_F32, PROFILER, View, _stream, rup
+
+
+def _esz(code: int) -> int:
+    return 2 if code == DT_BF16 else 4
 
 
 def correlation_views(f1: View, f2: View, out: View, c_norm: int, md: int, s2: int, slope: float, code: int) -> None:
-    """NHWC engine entry: out[..., D*D] = lrelu(corr(f1, f2)); f1/f2 channel extent padded with zeros to 8."""
+    """NHWC engine entry: out[..., D*D] = lrelu(corr(f1, f2)); f1/f2 channel extent padded with zeros to 8.
+    Algorithmic HBM bytes: both feature maps read once, the cost volume written once."""
     cp = rup(f1.C, 8)
     assert f1.c0 + cp <= f1.ld and f2.c0 + cp <= f2.ld and (f1.B, f1.H, f1.W) == (f2.B, f2.H, f2.W) == (out.B, out.H, out.W)
-    _lib.call("mireg_correlation_fwd", f1.ptr, f1.ld, f2.ptr, f2.ld, out.ptr, out.ld, f1.B, f1.H, f1.W, cp, c_norm, md, s2,
-              slope, code, _stream())
+    D = 2 * (md // s2) + 1
+    PROFILER.call("correlation_fwd", float(f1.rows) * (2 * f1.C + D * D) * _esz(code), f"corr-fwd C={f1.C} {f1.H}x{f1.W}",
+                  "mireg_correlation_fwd", f1.ptr, f1.ld, f2.ptr, f2.ld, out.ptr, out.ld, f1.B, f1.H, f1.W, cp, c_norm, md, s2,
+                  slope, code, _stream(), unit="B")
+
+
+def correlation_bwd_views(g: View, f1: View, f2: View, d1: View, d2: View, cp: int, c_norm: int, md: int, s2: int,
+                          acc1: int, acc2: int, code: int) -> None:
+    """d corr / d f1, d f2.  Algorithmic bytes: cost-volume gradient and both maps read once, both gradients written once."""
+    D = 2 * (md // s2) + 1
+    PROFILER.call("correlation_bwd", float(g.rows) * (D * D + 4 * c_norm) * _esz(code), f"corr-bwd C={c_norm} {f1.H}x{f1.W}",
+                  "mireg_correlation_bwd", g.ptr, g.ld, f1.ptr, f1.ld, f2.ptr, f2.ld, d1.ptr, d1.ld, d2.ptr, d2.ld,
+                  f1.B, f1.H, f1.W, cp, c_norm, md, s2, acc1, acc2, code, _stream(), unit="B")
 
 
 def pwc_warp_views(x: View, flow32: View, scale: float, out: View, code: int) -> None:
     cp = rup(x.C, 8)
     assert x.c0 + cp <= x.ld and out.c0 + cp <= out.ld
-    _lib.call("mireg_pwc_warp_fwd", x.ptr, x.ld, flow32.ptr, flow32.ld, float(scale), out.ptr, out.ld, x.B, x.H, x.W, cp,
-              code, _stream())
+    PROFILER.call("pwc_warp_fwd", float(x.rows) * (2 * x.C * _esz(code) + 8), f"warp-fwd C={x.C} {x.H}x{x.W}",
+                  "mireg_pwc_warp_fwd", x.ptr, x.ld, flow32.ptr, flow32.ld, float(scale), out.ptr, out.ld, x.B, x.H, x.W, cp,
+                  code, _stream(), unit="B")
+
+
+def pwc_warp_bwd_views(x: View, flow32: View, scale: float, dw: View, dx32: View, dflow32: View, C: int, code: int) -> None:
+    """Algorithmic bytes: features and their warped gradient read once, fp32 feature gradient + flow gradient written once."""
+    PROFILER.call("pwc_warp_bwd", float(x.rows) * (2 * C * _esz(code) + 4 * C + 16), f"warp-bwd C={C} {x.H}x{x.W}",
+                  "mireg_pwc_warp_bwd", x.ptr, x.ld, flow32.ptr, flow32.ld, float(scale), dw.ptr, dw.ld, dx32.ptr, dx32.ld,
+                  dflow32.ptr, dflow32.ld, x.B, x.H, x.W, C, code, _stream(), unit="B")
 
 
 class Correlation(nn.Module):

@@ -404,28 +404,6 @@ conv_halo_kernel(const mireg_conv_desc pd) {
   halo_tile<T, BM, BN, TY, TX>(pd);
 }
 
-// classes of different tap shapes in one launch (backward-data of a 5x5 / stride-2 convolution: 3x3, 3x2, 2x3, 2x2): blockIdx.y
-// picks the class, its shape picks a separately compiled tile function -- inlining the four unrolled loops into one kernel
-// makes the compiler hoist all their invariants at once (60-160 spilled SGPRs measured)
-typedef const __attribute__((address_space(4))) mireg_conv_desc* kernarg_desc_t;   // the descriptor where the launch put it
-template <typename T, int BM, int BN, int TY, int TX>
-__device__ __noinline__ void halo_tile_call(kernarg_desc_t kp) {
-  // read in place (scalar loads from the kernarg segment): a by-value or by-reference descriptor would go through scratch
-  const mireg_conv_desc& pd = *(const mireg_conv_desc*)kp;
-  halo_tile<T, BM, BN, TY, TX>(pd);
-}
-
-template <typename T, int BM, int BN>
-__global__ void __launch_bounds__(256, BM == 128 ? 2 : 1)
-conv_halo_multi_kernel(const mireg_conv_desc pd) {
-  const int code = pd.cls[blockIdx.y].taps_y * 4 + pd.cls[blockIdx.y].taps_x;
-  kernarg_desc_t kp = (kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr();   // pd is the only argument
-  if (code == 15) halo_tile_call<T, BM, BN, 3, 3>(kp);
-  else if (code == 14) halo_tile_call<T, BM, BN, 3, 2>(kp);
-  else if (code == 11) halo_tile_call<T, BM, BN, 2, 3>(kp);
-  else halo_tile_call<T, BM, BN, 2, 2>(kp);
-}
-
 // geometry of one class: does the halo path apply, and with how many tiles at BM rows per tile?
 bool class_ok(int gH, int gW, int ty, int tx, int bm, int bn, long* tiles_m, int n_img) {
   if (gW != 16 && gW != 32 && gW != 64) return false;
@@ -451,6 +429,11 @@ extern "C" int mireg_conv_halo_eligible(const mireg_conv_desc* p, long* tiles_ou
   if (p->N < 64) return 0;
   if (p->dtype != MIREG_DTYPE_BF16 && p->dtype != MIREG_DTYPE_F32) return 0;
   const int ncls = p->n_cls > 1 ? p->n_cls : 1;
+  // classes of different tap shapes (backward-data of 5x5 / stride 2) stay on the ring kernel: a one-launch dispatch over
+  // separately compiled tile functions was measured at 64-90 us stand-alone but 235 us next to the backward-weights stream
+  // (scratch for the calls, 248 VGPRs), and one launch per shape leaves 192-tile grids (profiles/README.md round 2)
+  for (int c = 1; c < ncls; ++c)
+    if (p->cls[c].taps_y != p->cls[0].taps_y || p->cls[c].taps_x != p->cls[0].taps_x) return 0;
   const int bn = (p->tile_n == 64 || p->N <= 64) ? 64 : 128;
   for (int b = 0; b < 2; ++b) {
     const int bm = b ? 256 : 128;
@@ -499,15 +482,7 @@ static int launch_halo_k(const mireg_conv_desc& p, long tiles_m, hipStream_t str
     if (ty0 == 2 && tx0 == 2) return launch_halo_shape<T, BM, BN, 2, 2>(p, tiles_m, bytes, stream);
     return MIREG_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_multi_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return MIREG_ERR_LAUNCH;
-    attr_set = true;
-  }
-  dim3 grid((unsigned)(tiles_m * ((p.N + BN - 1) / BN)), ncls, 1);
-  hipLaunchKernelGGL((conv_halo_multi_kernel<T, BM, BN>), grid, dim3(256), bytes, stream, p);
-  return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
+  return MIREG_ERR_UNSUPPORTED;                                      // mixed tap shapes: not eligible (mireg_conv_halo_eligible)
 }
 
 template <typename T>

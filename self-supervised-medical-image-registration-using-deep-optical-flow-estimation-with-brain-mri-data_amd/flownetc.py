@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .correlation import Correlation, correlation_views
+from .correlation import correlation_bwd_views, Correlation, correlation_views
 from .engine import BatchNormAct, F32, _stream, lrelu_bwd, nchw_to_view
 from .flownets import DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block
 
@@ -161,9 +161,7 @@ class FlowNetCEngine(PredictorEngineBase, FlowNetDecoderMixin):
             gcorr = self.din31.slice(32, 441)
             lrelu_bwd(gcorr, self.in31.slice(32, 441), SLOPE, self.ws)
             fa, fb = self.c3["a"], self.c3["b"]
-            _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, fa.ptr, fa.ld, fb.ptr, fb.ld, self.dc3["a"].ptr,
-                      self.dc3["a"].ld, self.dc3["b"].ptr, self.dc3["b"].ld, self.B, fa.H, fa.W, 256, 256, 20, 2, 1, 0,
-                      self.ws.code, _stream())
+            correlation_bwd_views(gcorr, fa, fb, self.dc3["a"], self.dc3["b"], 256, 256, 20, 2, 1, 0, self.ws.code)
             # siamese streams: same weights, wgrad slot per stream, shared BatchNorm parameter gradients accumulate
             cb("conv3", c[2].slice(0, 128), fa, dc[2].slice(0, 128), True, self.dc3["a"], "conv3@a", "conv3@a", 0, False)
             cb("conv2", self.c1["a"], c[2].slice(0, 128), self.dc1["a"], False, dc[2].slice(0, 128), "conv2@a", "conv2@a", 0, False)

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .correlation import Correlation, correlation_views, pwc_warp_views
+from .correlation import Correlation, correlation_bwd_views, correlation_views, pwc_warp_bwd_views, pwc_warp_views
 from .engine import F32, View, _stream, cast_from_f32, lrelu_bwd, nchw_to_view, zero_many_table
 from .flownets import PredictorEngineBase
 
@@ -197,19 +197,16 @@ class PWCEngine(PredictorEngineBase):
             cp = (FEAT_C[lvl] + 7) // 8 * 8
             if lvl == 6:
                 d1, d2 = dfeat(6, "a"), dfeat(6, "b")
-                _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, c1.ptr, c1.ld, c2.ptr, c2.ld, d1.ptr, d1.ld, d2.ptr,
-                          d2.ld, B, c1.H, c1.W, cp, FEAT_C[6], self.md, 1, 1, 1, code, st)
+                correlation_bwd_views(gcorr, c1, c2, d1, d2, cp, FEAT_C[6], self.md, 1, 1, 1, code)
                 return
             wv, dw, d1 = self.warped[lvl], self.dwarped[lvl], dfeat(lvl, "a")
-            _lib.call("mireg_correlation_bwd", gcorr.ptr, gcorr.ld, c1.ptr, c1.ld, wv.ptr, wv.ld, d1.ptr, d1.ld, dw.ptr, dw.ld,
-                      B, c1.H, c1.W, cp, FEAT_C[lvl], self.md, 1, 1, 1, code, st)
+            correlation_bwd_views(gcorr, c1, wv, d1, dw, cp, FEAT_C[lvl], self.md, 1, 1, 1, code)
             # c1 also sits in the concat
             gc1 = dX.slice(BASE + self.nd, FEAT_C[lvl])
             _lib.call("mireg_copy_channels", gc1.ptr, gc1.ld, d1.ptr, d1.ld, d1.rows, FEAT_C[lvl], 1, code, st)
             # warp backward -> d c2 (fp32 scatter) and d up_flow (fp32)
             dx32, duf32, d2 = self.dx32[lvl], self.dupflow32[lvl], dfeat(lvl, "b")
-            _lib.call("mireg_pwc_warp_bwd", c2.ptr, c2.ld, self.upflow32[lvl].ptr, self.upflow32[lvl].ld, FLOW_SCALE[lvl],
-                      dw.ptr, dw.ld, dx32.ptr, dx32.ld, duf32.ptr, duf32.ld, B, c2.H, c2.W, FEAT_C[lvl], code, st)
+            pwc_warp_bwd_views(c2, self.upflow32[lvl], FLOW_SCALE[lvl], dw, dx32, duf32, FEAT_C[lvl], code)
             cast_from_f32(d2.slice(0, FEAT_C[lvl]), dx32.slice(0, FEAT_C[lvl]), 1.0, 1.0)
             # up_flow / up_feat gradients: aligned 2-channel staging buffers (the concat slices sit at odd offsets)
             o = BASE + self.nd + FEAT_C[lvl]
