@@ -413,6 +413,13 @@ int mireg_copy_channels(const void* src, long ld_s, void* dst, long ld_d, long M
 int mireg_pwc_warp_bwd(const void* x, long ldx, const float* flow, long ldf, float flow_scale, const void* g, long ldg,
                        float* dx32, long lddx, float* dflow, long lddf, int B, int H, int W, int C, int dtype,
                        hipStream_t stream);
+/* The same gradients without fp32 scatter atomics (bit-reproducible): taps are bucketed by source pixel (integer atomics, scan,
+ * fill) and every source sums its bucket in ascending (destination, tap) order.  dx32 is OVERWRITTEN (all B*H*W*C values), dflow is
+ * added onto (hand in zeros).  Workspaces (caller-owned, P = B*H*W): ws_cnt P ints, ZERO on entry and zero again on exit; ws_off
+ * P + 1 + ceil(P/2048) ints; ws_entries 4*P 8-byte records.  C <= 512. */
+int mireg_pwc_warp_bwd_det(const void* x, long ldx, const float* flow, long ldf, float flow_scale, const void* g, long ldg,
+                           float* dx32, long lddx, float* dflow, long lddf, int* ws_cnt, int* ws_off, void* ws_entries,
+                           int B, int H, int W, int C, int dtype, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -46,11 +46,23 @@ def pwc_warp_views(x: View, flow32: View, scale: float, out: View, code: int) ->
                   code, _stream(), unit="B")
 
 
-def pwc_warp_bwd_views(x: View, flow32: View, scale: float, dw: View, dx32: View, dflow32: View, C: int, code: int) -> None:
-    """Algorithmic bytes: features and their warped gradient read once, fp32 feature gradient + flow gradient written once."""
+class WarpBwdWorkspace:
+    """Caller-owned scratch of mireg_pwc_warp_bwd_det for P = B*H*W pixels (counters start at zero and the kernel leaves them zero)."""
+
+    def __init__(self, P: int, device):
+        self.cnt = torch.zeros(P, device=device, dtype=torch.int32)
+        self.off = torch.zeros(P + 1 + (P + 2047) // 2048, device=device, dtype=torch.int32)
+        self.entries = torch.zeros(4 * P, 2, device=device, dtype=torch.int32)
+
+
+def pwc_warp_bwd_views(x: View, flow32: View, scale: float, dw: View, dx32: View, dflow32: View, C: int, code: int,
+                       wsb: WarpBwdWorkspace) -> None:
+    """Deterministic backward of the PWC warp (no fp32 scatter atomics).  Algorithmic bytes: features and their warped gradient
+    read once, fp32 feature gradient + flow gradient written once."""
     PROFILER.call("pwc_warp_bwd", float(x.rows) * (2 * C * _esz(code) + 4 * C + 16), f"warp-bwd C={C} {x.H}x{x.W}",
-                  "mireg_pwc_warp_bwd", x.ptr, x.ld, flow32.ptr, flow32.ld, float(scale), dw.ptr, dw.ld, dx32.ptr, dx32.ld,
-                  dflow32.ptr, dflow32.ld, x.B, x.H, x.W, C, code, _stream(), unit="B")
+                  "mireg_pwc_warp_bwd_det", x.ptr, x.ld, flow32.ptr, flow32.ld, float(scale), dw.ptr, dw.ld, dx32.ptr, dx32.ld,
+                  dflow32.ptr, dflow32.ld, wsb.cnt.data_ptr(), wsb.off.data_ptr(), wsb.entries.data_ptr(), x.B, x.H, x.W, C, code,
+                  _stream(), unit="B")
 
 
 class Correlation(nn.Module):

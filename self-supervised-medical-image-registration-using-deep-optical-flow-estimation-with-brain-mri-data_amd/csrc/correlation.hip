@@ -461,6 +461,189 @@ pwc_warp_bwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__
   }
 }
 
+// ---- deterministic PWC warp backward (reference PWC/models/PWCNet.py:143-179 through autograd) ------------------------------
+// d x is a scatter: destination pixel d adds w_t * g[d] to its four bilinear taps.  Instead of fp32 atomics (run-to-run
+// different sums) the taps are bucketed by SOURCE pixel with integer atomics only -- count, exclusive scan, fill -- and a
+// gather kernel sums every source's bucket in ascending (destination, tap) order: bit-reproducible, and the fp32 adds leave
+// the memory side.  Buckets longer than kDetSort entries (flows collapsing hundreds of pixels onto one) are summed in fill
+// order instead of paying an n^2 selection: reproducible whenever no bucket is that long.
+constexpr int kDetSort = 48;
+
+struct WarpTaps { int x0, y0; float wx0, wx1, wy0, wy1; bool live; };
+__device__ __forceinline__ WarpTaps warp_taps(const float* __restrict__ flow, long ldf_, float flow_scale, long pix, int xq, int yq,
+                                              int H, int W) {
+#pragma clang fp contract(off)
+  WarpTaps t;
+  const float u = flow[pix * ldf_] * flow_scale, v = flow[pix * ldf_ + 1] * flow_scale;
+  const float gx = 2.0f * ((float)xq + u) / (float)max(W - 1, 1) - 1.0f;
+  const float gy = 2.0f * ((float)yq + v) / (float)max(H - 1, 1) - 1.0f;
+  const float px = ((gx + 1.f) * (float)W - 1.f) / 2.f, py = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+  const float fx = floorf(px), fy = floorf(py);
+  t.x0 = (int)fx; t.y0 = (int)fy;
+  t.wx1 = px - fx; t.wy1 = py - fy; t.wx0 = 1.f - t.wx1; t.wy0 = 1.f - t.wy1;
+  float msk = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int xi = t.x0 + (k & 1), yi = t.y0 + (k >> 1);
+    if (xi >= 0 && xi < W && yi >= 0 && yi < H) msk += ((k & 1) ? t.wx1 : t.wx0) * ((k >> 1) ? t.wy1 : t.wy0);
+  }
+  t.live = msk >= 0.9999f;
+  return t;
+}
+
+// pass 1 (FILL = false): cnt[src] += 1 per live tap;  pass 3 (FILL = true): entries[off[src] + --cnt[src]] = (dst*4 + tap, weight)
+// -- the second pass counts cnt back down to zero, so the counters are clean for the next call
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+warp_bucket_kernel(const float* __restrict__ flow, long ldf_, float flow_scale, int* __restrict__ cnt, const int* __restrict__ off,
+                   int2* __restrict__ entries, int B, int H, int W) {
+  const long P = (long)B * H * W;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < P; pix += (long)gridDim.x * blockDim.x) {
+    const int xq = (int)(pix % W), yq = (int)((pix / W) % H);
+    const long img = pix / ((long)W * H);
+    const WarpTaps t = warp_taps(flow, ldf_, flow_scale, pix, xq, yq, H, W);
+    if (!t.live) continue;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xi = t.x0 + (k & 1), yi = t.y0 + (k >> 1);
+      if (xi < 0 || xi >= W || yi < 0 || yi >= H) continue;
+      const long tp = (img * H + yi) * W + xi;
+      if constexpr (!FILL) atomicAdd(cnt + tp, 1);
+      else {
+        const int slot = off[tp] + atomicSub(cnt + tp, 1) - 1;
+        const float wgt = ((k & 1) ? t.wx1 : t.wx0) * ((k >> 1) ? t.wy1 : t.wy0);
+        entries[slot] = make_int2((int)(pix * 4 + k), __float_as_int(wgt));
+      }
+    }
+  }
+}
+
+// exclusive scan of cnt[0..P) into off[0..P] in three small launches: block sums, scan of the block sums, local scans
+constexpr int kScanBlock = 2048;                                    // elements per block (256 threads x 8)
+__global__ void __launch_bounds__(256) scan_sums_kernel(const int* __restrict__ cnt, int* __restrict__ bsum, long P) {
+  __shared__ int red[256];
+  const long base = (long)blockIdx.x * kScanBlock;
+  int s = 0;
+  for (int i = threadIdx.x; i < kScanBlock; i += 256) s += base + i < P ? cnt[base + i] : 0;
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(256) scan_top_kernel(int* __restrict__ bsum, int nb) {    // in place, exclusive; nb <= 256 * 64
+  __shared__ int part[256];
+  const int per = (nb + 255) / 256, b0 = threadIdx.x * per;
+  int s = 0;
+  for (int i = 0; i < per; ++i) s += b0 + i < nb ? bsum[b0 + i] : 0;
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; } }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int i = 0; i < per && b0 + i < nb; ++i) { const int v = bsum[b0 + i]; bsum[b0 + i] = run; run += v; }
+}
+__global__ void __launch_bounds__(256) scan_local_kernel(const int* __restrict__ cnt, const int* __restrict__ bsum, int* __restrict__ off, long P) {
+  __shared__ int part[256];
+  const long base = (long)blockIdx.x * kScanBlock + threadIdx.x * 8;
+  int v[8], s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = base + i < P ? cnt[base + i] : 0; s += v[i]; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = bsum[blockIdx.x]; for (int i = 0; i < 256; ++i) { const int t = part[i]; part[i] = run; run += t; } }
+  __syncthreads();
+  int run = part[threadIdx.x];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { if (base + i < P) off[base + i] = run; run += v[i]; }
+  if (base <= P && P < base + 8) off[P] = run;                        // v[i] = 0 beyond P, so `run` is the grand total here
+}
+
+// dx32[src][c] = sum over the bucket of w * g[dst][c], ascending key order; one thread per (source pixel, channel granule)
+template <typename T>
+__global__ void __launch_bounds__(256)
+warp_gather_kernel(const T* __restrict__ g, long ldg, const int* __restrict__ off, const int2* __restrict__ entries,
+                   float* __restrict__ dx32, long lddx, long P, int C) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int cpr = C / V;
+  const long total = P * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)
+    const long src = i / cpr;
+    const int c0 = (int)(i - src * cpr) * V;
+    const int b0 = off[src], n = off[src + 1] - b0;
+    float acc[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+    int last = -1;
+    for (int it = 0; it < n; ++it) {
+      int2 e;
+      if (n <= kDetSort) {                                           // next entry in ascending key order
+        int best = 0x7fffffff, bw = 0;
+        for (int j = 0; j < n; ++j) { const int2 c = entries[b0 + j]; if (c.x > last && c.x < best) { best = c.x; bw = c.y; } }
+        e = make_int2(best, bw);
+        last = best;
+      } else e = entries[b0 + it];
+      const float w = __int_as_float(e.y);
+      float gv[V];
+      ld_granule(g + (long)(e.x >> 2) * ldg + c0, gv);
+#pragma unroll
+      for (int q = 0; q < V; ++q) acc[q] += gv[q] * w;
+    }
+    float* d = dx32 + src * lddx + c0;
+#pragma unroll
+    for (int q = 0; q < V; ++q) d[q] = acc[q];
+  }
+}
+
+// d flow (per destination pixel, no scatter): the channel granules of a pixel sit in consecutive lanes -> segmented shuffle sum
+template <typename T>
+__global__ void __launch_bounds__(256)
+warp_dflow_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ flow, long ldf_, float flow_scale,
+                  const T* __restrict__ g, long ldg, float* __restrict__ dflow, long lddf, int B, int H, int W, int C) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int cpr = C / V;
+  const long total = (long)B * H * W * cpr;
+  for (long i0 = (long)blockIdx.x * blockDim.x; i0 < total; i0 += (long)gridDim.x * blockDim.x) {   // wave-uniform trip count
+#pragma clang fp contract(off)
+    const bool active = i0 + threadIdx.x < total;
+    const long i = active ? i0 + threadIdx.x : total - 1;
+    const long pix = i / cpr;
+    const int c0 = (int)(i - pix * cpr) * V;
+    const int xq = (int)(pix % W), yq = (int)((pix / W) % H);
+    const long img = pix / ((long)W * H);
+    const WarpTaps t = warp_taps(flow, ldf_, flow_scale, pix, xq, yq, H, W);
+    const bool live = active && t.live;
+    float gv[V];
+    ld_granule(g + pix * ldg + c0, gv);
+    float dpx = 0.f, dpy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xi = t.x0 + (k & 1), yi = t.y0 + (k >> 1);
+      if (!live || xi < 0 || xi >= W || yi < 0 || yi >= H) continue;
+      const float wx = (k & 1) ? t.wx1 : t.wx0, wy = (k >> 1) ? t.wy1 : t.wy0;
+      const float dwx = (k & 1) ? 1.f : -1.f, dwy = (k >> 1) ? 1.f : -1.f;
+      float xv[V];
+      ld_granule(x + ((img * H + yi) * W + xi) * ldx + c0, xv);
+#pragma unroll
+      for (int q = 0; q < V; ++q) { dpx += gv[q] * xv[q] * dwx * wy; dpy += gv[q] * xv[q] * wx * dwy; }
+    }
+    const int lane = threadIdx.x & 63;
+    long key = active ? pix : -1 - (long)threadIdx.x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float ox = __shfl_down(dpx, o, 64), oy = __shfl_down(dpy, o, 64);
+      const long ok_ = __shfl_down(key, o, 64);
+      if (lane + o < 64 && ok_ == key) { dpx += ox; dpy += oy; }
+    }
+    const long prev = __shfl_up(key, 1, 64);
+    // a pixel's granules span at most two waves (C <= 512): two adds onto the caller's zeros commute exactly
+    if (live && (lane == 0 || prev != key)) {
+      atomicAdd(dflow + pix * lddf, dpx * flow_scale * (float)W / (float)max(W - 1, 1));
+      atomicAdd(dflow + pix * lddf + 1, dpy * flow_scale * (float)H / (float)max(H - 1, 1));
+    }
+  }
+}
+
 // dst[m][0..C) (+)= src[m][0..C)  (concat staging where a producer cannot write in place; any channel offset)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -558,6 +741,37 @@ int mireg_correlation_bwd(const void* g, long ldg, const void* f1, long ld1, con
     if (df1) hipLaunchKernelGGL((correlation_bwd_kernel<float, 0>), dim3((unsigned)gr), dim3(256), 0, stream, (const float*)g, ldg, (const float*)f2, ld2, (float*)df1, ldd1, B, H, W, C, c_norm, R, stride2, accumulate1);
     if (df2) hipLaunchKernelGGL((correlation_bwd_kernel<float, 1>), dim3((unsigned)gr), dim3(256), 0, stream, (const float*)g, ldg, (const float*)f1, ld1, (float*)df2, ldd2, B, H, W, C, c_norm, R, stride2, accumulate2);
   } else return MIREG_ERR_ARG;
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_pwc_warp_bwd_det(const void* x, long ldx, const float* flow, long ldf_, float flow_scale, const void* g, long ldg,
+                           float* dx32, long lddx, float* dflow, long lddf, int* ws_cnt, int* ws_off, void* ws_entries,
+                           int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(x && flow && g && dx32 && dflow && ws_cnt && ws_off && ws_entries && B > 0 && H > 0 && W > 0 && C > 0 && C <= 512 &&
+                  ldf_ >= 2 && lddf >= 2);
+  const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
+  MIREG_CHECK_ARG(C % V == 0 && ldx % V == 0 && ldg % V == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)g % 16 == 0);
+  MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
+  const long P = (long)B * H * W;
+  MIREG_CHECK_ARG(P * 4 < (1L << 31));
+  const int nb = (int)((P + kScanBlock - 1) / kScanBlock);
+  MIREG_CHECK_ARG(nb <= 256 * 64);
+  int* bsum = ws_off + P + 1;                                        // ws_off holds P + 1 + ceil(P / 2048) ints
+  const unsigned gp = (unsigned)((P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048);
+  hipLaunchKernelGGL((warp_bucket_kernel<false>), dim3(gp), dim3(256), 0, stream, flow, ldf_, flow_scale, ws_cnt, (const int*)nullptr, (int2*)nullptr, B, H, W);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, stream, (const int*)ws_cnt, bsum, P);
+  hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, stream, bsum, nb);
+  hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, stream, (const int*)ws_cnt, (const int*)bsum, ws_off, P);
+  hipLaunchKernelGGL((warp_bucket_kernel<true>), dim3(gp), dim3(256), 0, stream, flow, ldf_, flow_scale, ws_cnt, (const int*)ws_off, (int2*)ws_entries, B, H, W);
+  const long total = P * (C / V);
+  const unsigned gg = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == MIREG_DTYPE_BF16) {
+    hipLaunchKernelGGL((warp_gather_kernel<__bf16>), dim3(gg), dim3(256), 0, stream, (const __bf16*)g, ldg, (const int*)ws_off, (const int2*)ws_entries, dx32, lddx, P, C);
+    hipLaunchKernelGGL((warp_dflow_kernel<__bf16>), dim3(gg < 4096 ? gg : 4096), dim3(256), 0, stream, (const __bf16*)x, ldx, flow, ldf_, flow_scale, (const __bf16*)g, ldg, dflow, lddf, B, H, W, C);
+  } else {
+    hipLaunchKernelGGL((warp_gather_kernel<float>), dim3(gg), dim3(256), 0, stream, (const float*)g, ldg, (const int*)ws_off, (const int2*)ws_entries, dx32, lddx, P, C);
+    hipLaunchKernelGGL((warp_dflow_kernel<float>), dim3(gg < 4096 ? gg : 4096), dim3(256), 0, stream, (const float*)x, ldx, flow, ldf_, flow_scale, (const float*)g, ldg, dflow, lddf, B, H, W, C);
+  }
   MIREG_LAUNCH_RET();
 }
 

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .correlation import Correlation, correlation_bwd_views, correlation_views, pwc_warp_bwd_views, pwc_warp_views
+from .correlation import Correlation, WarpBwdWorkspace, correlation_bwd_views, correlation_views, pwc_warp_bwd_views, pwc_warp_views
 from .engine import F32, View, _stream, cast_from_f32, lrelu_bwd, nchw_to_view, zero_many_table
 from .flownets import PredictorEngineBase
 
@@ -138,11 +138,12 @@ class PWCEngine(PredictorEngineBase):
         self.dupflowT = {lvl: new(B, *hs[lvl], 2) for lvl in (5, 4, 3, 2)}
         self.dupfeatT = {lvl: new(B, *hs[lvl], 2) for lvl in (5, 4, 3, 2)}
         self.dupflow32 = {lvl: new(B, *hs[lvl], 2, dtype=F32, pad=2) for lvl in (5, 4, 3, 2)}
-        self.dx32 = {lvl: new(B, *hs[lvl], FEAT_C[lvl], dtype=F32) for lvl in (5, 4, 3, 2)}
+        self.dx32 = {lvl: new(B, *hs[lvl], FEAT_C[lvl], dtype=F32) for lvl in (5, 4, 3, 2)}      # overwritten by the warp backward
+        self.warp_ws = {lvl: WarpBwdWorkspace(B * hs[lvl][0] * hs[lvl][1], self.ws.device) for lvl in (5, 4, 3, 2)}
         self.ddc = [z(v) for v in self.dc]
         self._zero_list = ([v.buf for v in self.dx.values()] + [v.buf for v in self.dpyr.values()] +
                            [v.buf for v in self.dwarped.values()] + [v.buf for v in self.dupflow32.values()] +
-                           [v.buf for v in self.dx32.values()] + [v.buf for v in self.ddc])
+                           [v.buf for v in self.ddc])
         self.grads_ready = True
 
     def _conv_bwd(self, name: str, src: View, out: View, dout: View, dsrc, slot: int = 0, act: bool = True) -> None:
@@ -206,7 +207,7 @@ class PWCEngine(PredictorEngineBase):
             _lib.call("mireg_copy_channels", gc1.ptr, gc1.ld, d1.ptr, d1.ld, d1.rows, FEAT_C[lvl], 1, code, st)
             # warp backward -> d c2 (fp32 scatter) and d up_flow (fp32)
             dx32, duf32, d2 = self.dx32[lvl], self.dupflow32[lvl], dfeat(lvl, "b")
-            pwc_warp_bwd_views(c2, self.upflow32[lvl], FLOW_SCALE[lvl], dw, dx32, duf32, FEAT_C[lvl], code)
+            pwc_warp_bwd_views(c2, self.upflow32[lvl], FLOW_SCALE[lvl], dw, dx32, duf32, FEAT_C[lvl], code, self.warp_ws[lvl])
             cast_from_f32(d2.slice(0, FEAT_C[lvl]), dx32.slice(0, FEAT_C[lvl]), 1.0, 1.0)
             # up_flow / up_feat gradients: aligned 2-channel staging buffers (the concat slices sit at odd offsets)
             o = BASE + self.nd + FEAT_C[lvl]

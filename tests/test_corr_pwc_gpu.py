@@ -190,6 +190,48 @@ def test_pwc_warp_backward_vs_autograd():
     assert _rel(df.nchw(), f.grad) < 1e-4
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 32, 16, 16, 3.0), (3, 96, 24, 40, 9.0), (1, 128, 64, 64, 0.3), (2, 64, 8, 8, 40.0)])
+def test_pwc_warp_backward_deterministic_vs_autograd(shape, prec):
+    """mireg_pwc_warp_bwd_det (buckets by source pixel + ordered gather, no fp32 scatter atomics): equals autograd through the
+    oracle's warp, equals the atomic kernel up to fp32 summation order, is bit-identical between two runs, leaves its counters
+    zero, and survives flows that throw most pixels out of the image (scale 40) or pile them up (scale 9 on a 24x40 grid)."""
+    from mireg import _lib
+    from mireg.correlation import WarpBwdWorkspace
+    from mireg.engine import Workspace, _stream
+    B, C, H, W, mag = shape
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    ws = Workspace(torch.device(DEV), dt)
+    x = nets.analytic_input((B, C, H, W), seed=1) - 0.5
+    flo = (nets.analytic_input((B, 2, H, W), seed=2) - 0.5) * mag
+    g = nets.analytic_input((B, C, H, W), seed=3) - 0.5
+    if prec == "bf16":
+        x, g = x.bfloat16().float(), g.bfloat16().float()
+    a, f = x.clone().requires_grad_(), flo.clone().requires_grad_()
+    (oops.pwc_warp(a, f * 1.25) * g).sum().backward()
+    xv, gv = ws.new(B, H, W, C), ws.new(B, H, W, C)
+    xv.buf[...] = x.permute(0, 2, 3, 1).to(DEV); gv.buf[...] = g.permute(0, 2, 3, 1).to(DEV)
+    fv = ws.new(B, H, W, 2, dtype=torch.float32, pad=2); fv.buf[...] = flo.permute(0, 2, 3, 1).to(DEV)
+    wsb = WarpBwdWorkspace(B * H * W, torch.device(DEV))
+    outs = []
+    for _ in range(2):
+        dx = ws.new(B, H, W, C, dtype=torch.float32); dx.buf.fill_(7.0)              # dx32 is overwritten, not accumulated
+        df = ws.new(B, H, W, 2, dtype=torch.float32, pad=2)
+        _lib.call("mireg_pwc_warp_bwd_det", xv.ptr, xv.ld, fv.ptr, fv.ld, 1.25, gv.ptr, gv.ld, dx.ptr, dx.ld, df.ptr, df.ld,
+                  wsb.cnt.data_ptr(), wsb.off.data_ptr(), wsb.entries.data_ptr(), B, H, W, C, ws.code, _stream())
+        torch.cuda.synchronize()
+        outs.append((dx.nchw().clone(), df.nchw().clone()))
+        assert int(wsb.cnt.abs().max()) == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    scale_x, scale_f = max(a.grad.abs().max().item(), 1e-6), max(f.grad.abs().max().item(), 1e-6)
+    assert (outs[0][0].cpu() - a.grad).abs().max().item() <= 2e-5 * scale_x
+    assert (outs[0][1].cpu() - f.grad).abs().max().item() <= 2e-4 * scale_f
+    dx0 = ws.new(B, H, W, C, dtype=torch.float32); df0 = ws.new(B, H, W, 2, dtype=torch.float32, pad=2)
+    _lib.call("mireg_pwc_warp_bwd", xv.ptr, xv.ld, fv.ptr, fv.ld, 1.25, gv.ptr, gv.ld, dx0.ptr, dx0.ld, df0.ptr, df0.ld, B, H, W, C,
+              ws.code, _stream())
+    assert (dx0.nchw() - outs[0][0]).abs().max().item() <= 2e-5 * scale_x
+
+
 def test_pwcnet_training_gradients_match_oracle():
     """PWC-DC-Net fp32: gradients through dense estimators, cost volumes, warps, context net and the siamese pyramid."""
     import mireg

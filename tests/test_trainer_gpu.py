@@ -150,12 +150,11 @@ def test_dp2_bucketed_overlap_flownetc_on_one_gpu():
 
 
 def test_dp2_bucketed_overlap_pwc_on_one_gpu():
-    """PWC-DC-Net buckets (dc_conv + level 2 | levels 3..6 | pyramid).  Its warp backward scatters with fp32 atomics, so the
-    hand-averaged reference is compared through the update direction instead of element-wise: two identical single-process
-    runs already differ by cos = 0.97 after four Adam steps (noise-level gradients move by +-lr)."""
+    """PWC-DC-Net buckets (dc_conv + level 2 | levels 3..6 | pyramid).  Its warp backward is the bucketed, ordered gather
+    (mireg_pwc_warp_bwd_det): no fp32 scatter atomics are left on the path, so the comparison is as strict as FlowNetS's."""
     import socket, tempfile
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    _dp_compare("pwc", 128, port, tempfile.mkdtemp(prefix="mireg_dp_"), strict=False)
+    _dp_compare("pwc", 128, port, tempfile.mkdtemp(prefix="mireg_dp_"))
 
 
 def _dp_compare(name, size, port, tmp, strict=True):
