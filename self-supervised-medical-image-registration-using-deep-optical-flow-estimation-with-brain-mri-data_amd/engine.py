@@ -95,6 +95,18 @@ def zero_many_table(bufs: Sequence[torch.Tensor], device):
     return upload_table(jobs, device), len(jobs), u
 
 
+def zero_tensors(bufs: Sequence[torch.Tensor]) -> None:
+    """Zero whole tensors with ONE mireg_zero_many launch (the tables are cached per set of buffers): the step's only fills."""
+    key = tuple(b.data_ptr() for b in bufs)
+    tab = _ZERO_TABLES.get(key)
+    if tab is None:
+        tab = _ZERO_TABLES[key] = zero_many_table(bufs, bufs[0].device)
+    _lib.call("mireg_zero_many", tab[0].data_ptr(), tab[1], tab[2], _stream())
+
+
+_ZERO_TABLES: Dict[tuple, tuple] = {}
+
+
 class Pack3dJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p * 8), ("Co", ctypes.c_int), ("Ci", ctypes.c_int),
                 ("Cop", ctypes.c_int), ("kd", ctypes.c_int), ("kh", ctypes.c_int), ("kw", ctypes.c_int),

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import (DT_BF16, F32, BatchNormAct, ConvLayer, View, Workspace, _stream, assign_tiles, cast_from_f32,
+from .engine import (DT_BF16, F32, BatchNormAct, ConvLayer, View, Workspace, _stream, assign_tiles, cast_from_f32, zero_tensors,
                      lrelu_bwd, nchw_to_view, upload_table)
 
 ENCODER = [  # name, cin, cout, k, stride   (FlowNetS/FlowNetS.py:17-26)
@@ -286,7 +286,7 @@ class FlowNetDecoderMixin:
             if lvl == 2 and g0 is not None:
                 d32 = self.dflow32
                 if gt is None:
-                    d32.buf.zero_()
+                    zero_tensors([d32.buf])
                 else:
                     nchw_to_view(gt.contiguous(), 0, 2, d32)
                 g0c = g0.contiguous()
@@ -294,7 +294,7 @@ class FlowNetDecoderMixin:
                           d32.H * d32.W * 2, 1, 2, 2 * 256 * 256, 256 * 256, 1, 0, 1.0, st)
                 cast_from_f32(dst, d32)
             elif gt is None:
-                dst.buf.zero_()
+                zero_tensors([dst.buf])
             else:
                 nchw_to_view(gt.contiguous(), 0, 2, dst)
 

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _lib
 from .affine3d import Conv3dLayer, Vol
-from .engine import BatchNormAct, Workspace, _stream, assign_tiles, rup, upload_table
+from .engine import BatchNormAct, Workspace, _stream, assign_tiles, rup, upload_table, zero_tensors
 from .volume import resize_trilinear, stn3d
 
 ENC = [("conv1", 7, 2), ("conv2", 5, 2), ("conv3", 5, 2), ("conv3_1", 3, 1), ("conv4", 3, 2), ("conv4_1", 3, 1),
@@ -194,7 +194,7 @@ class FlowNetS3D(nn.Module):
         for g, lv in zip(gflows, (2, 3, 4, 5, 6)):
             gf = e["gflow"][lv]
             if g is None:
-                gf.buf.zero_()
+                zero_tensors([gf.buf])
                 continue
             g = g.float().contiguous()
             nv = dims[lv][0] * dims[lv][1] * dims[lv][2]

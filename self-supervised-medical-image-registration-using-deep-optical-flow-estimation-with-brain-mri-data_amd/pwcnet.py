@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _lib
 from .correlation import Correlation, WarpBwdWorkspace, correlation_bwd_views, correlation_views, pwc_warp_bwd_views, pwc_warp_views
-from .engine import F32, View, _stream, cast_from_f32, lrelu_bwd, nchw_to_view, zero_many_table
+from .engine import F32, View, _stream, cast_from_f32, lrelu_bwd, nchw_to_view, zero_many_table, zero_tensors
 from .flownets import PredictorEngineBase
 
 SLOPE = 0.1
@@ -178,7 +178,7 @@ class PWCEngine(PredictorEngineBase):
         _lib.call("mireg_zero_many", self._zero_tab[0].data_ptr(), self._zero_tab[1], self._zero_tab[2], st)
         for lvl in range(0, 7):                                   # loss gradients of the seven flows
             if g[lvl] is None:
-                self.dflowT[lvl].buf.zero_()
+                zero_tensors([self.dflowT[lvl].buf])
             else:
                 nchw_to_view(g[lvl].contiguous(), 0, 2, self.dflowT[lvl])
         feat = lambda lvl, s: self.pyr[(lvl, s, 2)]

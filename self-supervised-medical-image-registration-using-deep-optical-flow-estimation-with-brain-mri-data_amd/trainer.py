@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import dist as mdist
-from .engine import PROFILER, AdamJob, F32, TailJob, WoptJob, _stream, upload_table
+from .engine import PROFILER, AdamJob, F32, TailJob, WoptJob, _stream, upload_table, zero_tensors
 from .ops import SLOTS
 
 
@@ -82,7 +82,7 @@ class FusedRegLoss:
         B, H, W, st = self.B, self.H, self.W, _stream()
         HW = H * W
         fixed_ptr, moving_ptr = x.data_ptr(), x.data_ptr() + HW * 4
-        self.sums.zero_()
+        zero_tensors([self.sums])                           # HIP fill (no ATen launch inside the step)
         if self.fused:
             tab, blocks = self._table(flows)
             npx = sum(B * h * w for h, w in self.sizes)          # algorithmic HBM bytes: DESIGN.md section 6
