@@ -530,14 +530,14 @@ __global__ void __launch_bounds__(256) scan_sums_kernel(const int* __restrict__ 
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
 }
-__global__ void __launch_bounds__(256) scan_top_kernel(int* __restrict__ bsum, int nb) {    // in place, exclusive; nb <= 256 * 64
+__global__ void __launch_bounds__(256) scan_top_kernel(int* __restrict__ bsum, int nb, int* __restrict__ total) {    // in place, exclusive; nb <= 256 * 64
   __shared__ int part[256];
   const int per = (nb + 255) / 256, b0 = threadIdx.x * per;
   int s = 0;
   for (int i = 0; i < per; ++i) s += b0 + i < nb ? bsum[b0 + i] : 0;
   part[threadIdx.x] = s;
   __syncthreads();
-  if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; } }
+  if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; } *total = run; }
   __syncthreads();
   int run = part[threadIdx.x];
   for (int i = 0; i < per && b0 + i < nb; ++i) { const int v = bsum[b0 + i]; bsum[b0 + i] = run; run += v; }
@@ -555,7 +555,6 @@ __global__ void __launch_bounds__(256) scan_local_kernel(const int* __restrict__
   int run = part[threadIdx.x];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { if (base + i < P) off[base + i] = run; run += v[i]; }
-  if (base <= P && P < base + 8) off[P] = run;                        // v[i] = 0 beyond P, so `run` is the grand total here
 }
 
 // dx32[src][c] = sum over the bucket of w * g[dst][c], ascending key order; one thread per (source pixel, channel granule)
@@ -760,7 +759,7 @@ int mireg_pwc_warp_bwd_det(const void* x, long ldx, const float* flow, long ldf_
   const unsigned gp = (unsigned)((P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048);
   hipLaunchKernelGGL((warp_bucket_kernel<false>), dim3(gp), dim3(256), 0, stream, flow, ldf_, flow_scale, ws_cnt, (const int*)nullptr, (int2*)nullptr, B, H, W);
   hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, stream, (const int*)ws_cnt, bsum, P);
-  hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, stream, bsum, nb);
+  hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, stream, bsum, nb, ws_off + P);        // off[P] = number of entries
   hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, stream, (const int*)ws_cnt, (const int*)bsum, ws_off, P);
   hipLaunchKernelGGL((warp_bucket_kernel<true>), dim3(gp), dim3(256), 0, stream, flow, ldf_, flow_scale, ws_cnt, (const int*)ws_off, (int2*)ws_entries, B, H, W);
   const long total = P * (C / V);
