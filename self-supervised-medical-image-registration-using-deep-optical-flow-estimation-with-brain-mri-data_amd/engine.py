@@ -97,7 +97,7 @@ def zero_many_table(bufs: Sequence[torch.Tensor], device):
 
 def zero_tensors(bufs: Sequence[torch.Tensor]) -> None:
     """Zero whole tensors with ONE mireg_zero_many launch (the tables are cached per set of buffers): the step's only fills."""
-    key = tuple(b.data_ptr() for b in bufs)
+    key = tuple((b.data_ptr(), b.numel() * b.element_size()) for b in bufs)   # (address, bytes): an address can be re-used
     tab = _ZERO_TABLES.get(key)
     if tab is None:
         tab = _ZERO_TABLES[key] = zero_many_table(bufs, bufs[0].device)

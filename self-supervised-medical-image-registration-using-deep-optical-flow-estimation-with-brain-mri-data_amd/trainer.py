@@ -458,6 +458,20 @@ class RegistrationTrainer:
         return self.loss.out4
 
     def _capture(self) -> None:
+        # A cyclic-garbage collection that fires while a stream is capturing can free device memory or another trainer's graphs
+        # inside the capture (hipFree / hipGraphExecDestroy are illegal there and abort the process): collect now, then keep the
+        # collector off until the capture is over.
+        import gc
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_graphs()
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _capture_graphs(self) -> None:
         torch.cuda.synchronize()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
