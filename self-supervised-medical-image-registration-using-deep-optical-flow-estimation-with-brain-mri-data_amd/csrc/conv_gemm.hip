@@ -285,6 +285,7 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
   if (loads_per_tile == A_PW + B_PW) {                               // every wave of 128/64-wide tiles: immediate count
     for (; it < steady; ++it) {
       wait_vmcnt<2 * (A_PW + B_PW)>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own fragment reads done before another wave's DMA re-fills the stage
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       issue((it + STAGES - 1) % STAGES);
@@ -293,6 +294,7 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
   } else {
     for (; it < steady; ++it) {
       wait_vmcnt_dyn(2 * loads_per_tile);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own fragment reads done before another wave's DMA re-fills the stage
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       issue((it + STAGES - 1) % STAGES);
@@ -301,6 +303,7 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
   }
   for (; it < nk; ++it) {                                            // drain: nothing left to issue
     wait_vmcnt_dyn(min(STAGES - 2, nk - 1 - it) * loads_per_tile);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     compute(it % STAGES);
@@ -841,6 +844,7 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   const int steady = nk - (STAGES - 1);
   for (; it < steady; ++it) {
     wait_vmcnt<(STAGES - 2) * 4>();                                // STAGES-2 younger tiles x 4 DMAs stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue((it + STAGES - 1) % STAGES);
@@ -848,6 +852,7 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   }
   for (; it < nk; ++it) {
     wait_vmcnt_dyn(min(STAGES - 2, nk - 1 - it) * 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     compute(it % STAGES);

@@ -298,6 +298,7 @@ __device__ __forceinline__ void halo_tile(const mireg_conv_desc& pd) {
 #define MIREG_HALO_STEP(t)                                                             \
       if constexpr ((t) < TAPS) {                                                      \
         wait_vmcnt<YOUNG>();                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* own fragment reads done before the ring is re-filled */ \
         __builtin_amdgcn_s_barrier();                                                  \
         asm volatile("" ::: "memory");                                                 \
         issue_next_B();                                                                \

@@ -204,6 +204,7 @@ __device__ __forceinline__ void wgrad_halo_tile(const WgArgs& a) {
 #define MIREG_WG_STEP(j)                                                                           \
     if constexpr ((j) < SPC) {                                                                     \
       wait_vmcnt<YOUNG>();                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* own fragment reads done before the ring is re-filled */ \
       __builtin_amdgcn_s_barrier();                                                                \
       asm volatile("" ::: "memory");                                                               \
       issue_dy();                                                                                  \
