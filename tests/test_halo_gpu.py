@@ -126,7 +126,8 @@ def test_halo_stride2_backward_data_and_deconv_forward(case, prec):
             assert _rel(outs[tag], ref) < tol, tag
     finally:
         engine.FORCE_ALGO = None
-    assert len(outs) >= 2
+    # classes of different tap shapes (5x5 / stride 2: 3x3, 3x2, 2x3, 2x2) stay on the ring kernel: the halo path refuses them
+    assert (len(outs) >= 2) if k == 4 else (set(outs) == {"ring"})
     ulp = 1e-5 if prec == "fp32" else 2 ** -7
     for tag in outs:
         assert _rel(outs[tag], outs["ring"]) < ulp, tag
