@@ -313,6 +313,19 @@ int mireg_thin_shift_sum(const float* z, long ld_z, const float* bias, void* y, 
                          int W, int dtype, hipStream_t stream);
 int mireg_thin_gather18(const void* dy, long ld_dy, void* dz, long ld_dz, int B, int H, int W, int dtype, hipStream_t stream);
 
+/* ---- the 2 -> 2 channel flow / feature upsamplers ConvTranspose2d(2, 2, 4, 2, 1) (FlowNetS/FlowNetS.py:37-40,
+ * flownet2/networks/FlowNetC.py:53-56, PWC/models/PWCNet.py upfeat / deconv): pixel-parallel kernels on the fp32 master
+ * weight w = the module's weight [2][2][4][4] (no packs).  x_coarse / dx_coarse: NHWC (B, Hc, Wc, ld_c), y_fine / g_fine:
+ * (B, 2Hc, 2Wc, ld_f), two channels each.  bwd_weights writes mireg_tiny_deconv_blocks(B,Hc,Wc) partial slabs in the standard
+ * layout [blk][2][16*Cpad] (pad slots untouched: hand in zeroed memory), summed by mireg_wgrad_reduce / mireg_unpack_wgrad. */
+int mireg_tiny_deconv_blocks(int B, int Hc, int Wc);
+int mireg_tiny_deconv_fwd(const void* x_coarse, long ld_c, const float* w, const float* bias, void* y_fine, long ld_f, int B, int Hc,
+                          int Wc, int dtype, hipStream_t stream);
+int mireg_tiny_deconv_bwd_data(const void* g_fine, long ld_f, const float* w, void* dx_coarse, long ld_c, int accumulate, int B,
+                               int Hc, int Wc, int dtype, hipStream_t stream);
+int mireg_tiny_deconv_bwd_weights(const void* g_fine, long ld_f, const void* x_coarse, long ld_c, float* slab, int nblocks, int Cpad,
+                                  int B, int Hc, int Wc, int dtype, hipStream_t stream);
+
 /* ---- 7x7 / stride 2 / pad 3 input convolutions with 1 or 2 input channels and 64 outputs, bf16 (FlowNetS conv1
  * `FlowNetS/FlowNetS.py:18`, FlowNetC's siamese conv1 `flownet2/networks/FlowNetC.py:20`): K re-ordered to (ky, kx, ci)
  * so the input patch is staged once per 8x16 output tile.  x = NHWC bf16 input (channels 0..Ci-1 real), w = the

@@ -359,6 +359,116 @@ thin_gather18_kernel(const T* __restrict__ dy, long ld_dy, T* __restrict__ dz, l
   }
 }
 
+// ---- the 2 -> 2 channel flow / feature upsamplers, ConvTranspose2d(2, 2, 4, 2, 1) (FlowNetS/FlowNetS.py:37-40,
+// flownet2/networks/FlowNetC.py:53-56, PWC/models/PWCNet.py:80,95,...): a few MFLOP each, 12 GEMM launches per FlowNetS step
+// when run through the 128-wide tiles.  Here: one thread per pixel on the fp32 master weight Wc[co][ci][ky][kx] (the Conv2d
+// weight of the adjoint, stride-2 convolution fine(ci) -> coarse(co); 32 floats, read through the scalar cache).
+template <typename T>
+__global__ void __launch_bounds__(256)
+tiny_deconv_fwd_kernel(const T* __restrict__ xc, long ld_c, const float* __restrict__ w, const float* __restrict__ bias,
+                       T* __restrict__ yf, long ld_f, int B, int Hc, int Wc_) {
+  const int Hf = 2 * Hc, Wf = 2 * Wc_;
+  const long n = (long)B * Hf * Wf;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(p % Wf), iy = (int)((p / Wf) % Hf);
+    const long b = p / ((long)Wf * Hf);
+    float a0 = bias ? bias[0] : 0.f, a1 = bias ? bias[1] : 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+      const int ky = ((iy + 1) & 1) + 2 * ty, oy = (iy + 1 - ky) >> 1;          // fine row iy receives taps ky = (iy+1) mod 2, +2
+      if ((unsigned)oy >= (unsigned)Hc) continue;
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        const int kx = ((ix + 1) & 1) + 2 * tx, ox = (ix + 1 - kx) >> 1;
+        if ((unsigned)ox >= (unsigned)Wc_) continue;
+        const T* src = xc + ((b * Hc + oy) * Wc_ + ox) * ld_c;
+        const float c0 = (float)src[0], c1 = (float)src[1];
+        a0 += c0 * w[(0 * 2 + 0) * 16 + ky * 4 + kx] + c1 * w[(1 * 2 + 0) * 16 + ky * 4 + kx];
+        a1 += c0 * w[(0 * 2 + 1) * 16 + ky * 4 + kx] + c1 * w[(1 * 2 + 1) * 16 + ky * 4 + kx];
+      }
+    }
+    T* d = yf + p * ld_f;
+    d[0] = (T)a0; d[1] = (T)a1;
+  }
+}
+
+// backward-data of the upsampler = the stride-2 convolution itself: coarse[o][co] (+)= sum fine[2o + k - 1][ci] * Wc[co][ci][k]
+template <typename T>
+__global__ void __launch_bounds__(256)
+tiny_conv_fwd_kernel(const T* __restrict__ xf, long ld_f, const float* __restrict__ w, T* __restrict__ yc, long ld_c, int accumulate,
+                     int B, int Hc, int Wc_) {
+  const int Hf = 2 * Hc, Wf = 2 * Wc_;
+  const long n = (long)B * Hc * Wc_;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(p % Wc_), oy = (int)((p / Wc_) % Hc);
+    const long b = p / ((long)Wc_ * Hc);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int iy = 2 * oy + ky - 1;
+      if ((unsigned)iy >= (unsigned)Hf) continue;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int ix = 2 * ox + kx - 1;
+        if ((unsigned)ix >= (unsigned)Wf) continue;
+        const T* src = xf + ((b * Hf + iy) * Wf + ix) * ld_f;
+        const float f0 = (float)src[0], f1 = (float)src[1];
+        a0 += f0 * w[(0 * 2 + 0) * 16 + ky * 4 + kx] + f1 * w[(0 * 2 + 1) * 16 + ky * 4 + kx];
+        a1 += f0 * w[(1 * 2 + 0) * 16 + ky * 4 + kx] + f1 * w[(1 * 2 + 1) * 16 + ky * 4 + kx];
+      }
+    }
+    T* d = yc + p * ld_c;
+    if (accumulate) { a0 += (float)d[0]; a1 += (float)d[1]; }
+    d[0] = (T)a0; d[1] = (T)a1;
+  }
+}
+
+// backward-weights: slab[blk][co][(ky*4+kx)*Cpad + ci] = sum over the block's coarse pixels of dy[o][co] * fine[2o + k - 1][ci]
+// (fixed pixel ranges per block, fixed-order tree sum: deterministic); pad slots are never written (zeroed slabs)
+template <typename T>
+__global__ void __launch_bounds__(256)
+tiny_wgrad_kernel(const T* __restrict__ xf, long ld_f, const T* __restrict__ dyc, long ld_c, float* __restrict__ slab, int Cpad,
+                  int B, int Hc, int Wc_) {
+  __shared__ float red[4][64];
+  const int Hf = 2 * Hc, Wf = 2 * Wc_;
+  const long n = (long)B * Hc * Wc_;
+  const long per = (n + gridDim.x - 1) / gridDim.x, p0 = (long)blockIdx.x * per, p1 = min(n, p0 + per);
+  float acc[64];                                                      // [co][ci][ky][kx]
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+  for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+    const int ox = (int)(p % Wc_), oy = (int)((p / Wc_) % Hc);
+    const long b = p / ((long)Wc_ * Hc);
+    const float g0 = (float)dyc[p * ld_c], g1 = (float)dyc[p * ld_c + 1];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int iy = 2 * oy + ky - 1;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int ix = 2 * ox + kx - 1;
+        float f0 = 0.f, f1 = 0.f;
+        if ((unsigned)iy < (unsigned)Hf && (unsigned)ix < (unsigned)Wf) {
+          const T* src = xf + ((b * Hf + iy) * Wf + ix) * ld_f;
+          f0 = (float)src[0]; f1 = (float)src[1];
+        }
+        acc[(0 * 2 + 0) * 16 + ky * 4 + kx] += g0 * f0; acc[(0 * 2 + 1) * 16 + ky * 4 + kx] += g0 * f1;
+        acc[(1 * 2 + 0) * 16 + ky * 4 + kx] += g1 * f0; acc[(1 * 2 + 1) * 16 + ky * 4 + kx] += g1 * f1;
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const float v = wave_sum(acc[i]);
+    if (lane == 0) red[wid][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int i = threadIdx.x, co = i >> 5, ci = (i >> 4) & 1, tap = i & 15;
+    slab[(long)blockIdx.x * 2 * 16 * Cpad + (long)co * 16 * Cpad + tap * Cpad + ci] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+
 extern "C" {
 
 int mireg_thin_conv_fwd(const void* x, long ld_x, const void* w, long ld_w, const float* bias, void* y, long ld_y,
@@ -451,6 +561,50 @@ int mireg_thin_gather18(const void* dy, long ld_dy, void* dz, long ld_dz, int B,
     hipLaunchKernelGGL((thin_gather18_kernel<__bf16>), dim3(grid), dim3(256), 0, stream, (const __bf16*)dy, ld_dy, (__bf16*)dz, ld_dz, B, H, W);
   else
     hipLaunchKernelGGL((thin_gather18_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)dy, ld_dy, (float*)dz, ld_dz, B, H, W);
+  MIREG_LAUNCH_RET();
+}
+
+
+int mireg_tiny_deconv_blocks(int B, int Hc, int Wc) {
+  const long n = (long)B * Hc * Wc;
+  const long g = (n + 1023) / 1024;
+  return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));
+}
+
+int mireg_tiny_deconv_fwd(const void* x_coarse, long ld_c, const float* w, const float* bias, void* y_fine, long ld_f, int B, int Hc,
+                          int Wc, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(x_coarse && w && y_fine && ld_c >= 2 && ld_f >= 2 && B > 0 && Hc > 0 && Wc > 0);
+  MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
+  const long n = (long)B * Hc * Wc * 4;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((tiny_deconv_fwd_kernel<__bf16>), dim3(grid), dim3(256), 0, stream, (const __bf16*)x_coarse, ld_c, w, bias, (__bf16*)y_fine, ld_f, B, Hc, Wc);
+  else
+    hipLaunchKernelGGL((tiny_deconv_fwd_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)x_coarse, ld_c, w, bias, (float*)y_fine, ld_f, B, Hc, Wc);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_tiny_deconv_bwd_data(const void* g_fine, long ld_f, const float* w, void* dx_coarse, long ld_c, int accumulate, int B,
+                               int Hc, int Wc, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(g_fine && w && dx_coarse && ld_c >= 2 && ld_f >= 2 && B > 0 && Hc > 0 && Wc > 0);
+  MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
+  const long n = (long)B * Hc * Wc;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((tiny_conv_fwd_kernel<__bf16>), dim3(grid), dim3(256), 0, stream, (const __bf16*)g_fine, ld_f, w, (__bf16*)dx_coarse, ld_c, accumulate, B, Hc, Wc);
+  else
+    hipLaunchKernelGGL((tiny_conv_fwd_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)g_fine, ld_f, w, (float*)dx_coarse, ld_c, accumulate, B, Hc, Wc);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_tiny_deconv_bwd_weights(const void* g_fine, long ld_f, const void* x_coarse, long ld_c, float* slab, int nblocks, int Cpad,
+                                  int B, int Hc, int Wc, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(g_fine && x_coarse && slab && ld_c >= 2 && ld_f >= 2 && B > 0 && Hc > 0 && Wc > 0 && Cpad >= 2);
+  MIREG_CHECK_ARG(nblocks == mireg_tiny_deconv_blocks(B, Hc, Wc) && (dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32));
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((tiny_wgrad_kernel<__bf16>), dim3(nblocks), dim3(256), 0, stream, (const __bf16*)g_fine, ld_f, (const __bf16*)x_coarse, ld_c, slab, Cpad, B, Hc, Wc);
+  else
+    hipLaunchKernelGGL((tiny_wgrad_kernel<float>), dim3(nblocks), dim3(256), 0, stream, (const float*)g_fine, ld_f, (const float*)x_coarse, ld_c, slab, Cpad, B, Hc, Wc);
   MIREG_LAUNCH_RET();
 }
 

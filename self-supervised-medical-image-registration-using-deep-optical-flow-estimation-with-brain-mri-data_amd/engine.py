@@ -332,6 +332,8 @@ class ConvLayer:
         # two-channel 3x3 heads (predict_flow): vector-ALU streaming kernels instead of a 2-column GEMM
         self.thin = USE_THIN and (self.Co, self.kh, self.kw, self.s, self.p, self.d) == (2, 3, 3, 1, 1, 1)
         self.thin_gemm = False                             # decided in plan_wgrad (forward decides per call)
+        # 2 -> 2 channel ConvTranspose2d(4, 2, 1) upsamplers: pixel-parallel kernels on the master weight (csrc/thin_conv.hip)
+        self.tiny = USE_THIN and (self.Co, self.Ci, self.kh, self.kw, self.s, self.p, self.d) == (2, 2, 4, 4, 2, 1, 1)
         # 1-2 channel 7x7/s2 input convolutions: patch-staged kernels with K = (ky, kx, ci) (stem_conv.hip)
         self.stem = (USE_STEM and ws.code == DT_BF16 and (self.kh, self.kw, self.s, self.p, self.d) == (7, 7, 2, 3, 1)
                      and self.Ci <= 2 and self.Co == 64)
@@ -457,6 +459,10 @@ class ConvLayer:
         Wo = (x.W + 2 * self.p - self.d * (self.kw - 1) - 1) // self.s + 1
         out = y if y is not None else y32
         assert (out.H, out.W) == (Ho, Wo), (self.name, (out.H, out.W), (Ho, Wo))
+        if self.tiny and y is not None and y32 is None and slope == 1.0 and not bias and (x.H, x.W) == (2 * Ho, 2 * Wo):
+            _lib.call("mireg_tiny_deconv_bwd_data", x.ptr, x.ld, self.weight.data_ptr(), y.ptr, y.ld, int(accumulate), x.B, Ho, Wo,
+                      self.ws.code, _stream())
+            return
         if self.stem and y is not None and y32 is None and not accumulate:
             PROFILER.call("stem_conv_fwd", 2.0 * x.B * Ho * Wo * self.Co * 49 * self.Ci, f"{self.name}:stem-fwd",
                           "mireg_stem_conv_fwd", x.ptr, x.ld, self.packF.data_ptr(), self.Kf, self.Cip,
@@ -512,6 +518,11 @@ class ConvLayer:
         (only exact divisions contribute).  out has the LARGER spatial size."""
         assert g.C <= self.Cop and g.c0 + self.Cop <= g.ld, (self.name, g.C, self.Co, g.ld)
         o = out if out is not None else y32
+        if self.tiny and out is not None and y32 is None and slope == 1.0 and not accumulate and (out.H, out.W) == (2 * g.H, 2 * g.W):
+            _lib.call("mireg_tiny_deconv_fwd", g.ptr, g.ld, self.weight.data_ptr(),
+                      self.bias.data_ptr() if (bias and self.bias is not None) else None, out.ptr, out.ld, g.B, g.H, g.W,
+                      self.ws.code, _stream())
+            return
         if self.thin and out is not None and y32 is None and slope == 1.0 and not bias:
             PROFILER.call("thin_conv_dgrad", 2.0 * g.B * g.H * g.W * 2 * 9 * self.Ci, f"{self.name}:thin-dgrad",
                           "mireg_thin_conv_dgrad", g.ptr, g.ld, self.packF.data_ptr(), self.Kf, out.ptr, out.ld,
@@ -560,7 +571,9 @@ class ConvLayer:
         tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
         nk = (dy.rows + bk - 1) // bk
         self.thin_gemm = self.thin and dy.rows >= THIN_GEMM_ROWS
-        if self.thin_gemm:                                   # 1x1 backward-weights GEMM on (dz, x): 128-column tiles x pixel splits
+        if self.tiny:
+            self.wgrad_split = _lib.lib().mireg_tiny_deconv_blocks(dy.B, dy.H, dy.W)
+        elif self.thin_gemm:                                   # 1x1 backward-weights GEMM on (dz, x): 128-column tiles x pixel splits
             self.wgrad_split = max(1, min(512 // ((self.Cip + 127) // 128), nk // 8, 192))
         elif self.thin:
             self.wgrad_split = _lib.lib().mireg_thin_conv_wgrad_tiles(dy.B, dy.H, dy.W, self.Cip, self.ws.code, None)
@@ -651,6 +664,10 @@ class ConvLayer:
         if self.wgrad_slab is None:
             self.plan_wgrad(x, dy)
         assert x.C <= self.Cip and x.c0 + self.Cip <= x.ld and dy.c0 + rup(self.Co, 8) <= dy.ld, self.name
+        if self.tiny:
+            _lib.call("mireg_tiny_deconv_bwd_weights", x.ptr, x.ld, dy.ptr, dy.ld, self.wgrad_slab[slot * self.wgrad_split].data_ptr(),
+                      self.wgrad_split, self.Cip, dy.B, dy.H, dy.W, self.ws.code, _stream())
+            return
         if self.thin and self.thin_gemm:
             self._thin_gemm_wgrad(x, dy, slot)
             return
