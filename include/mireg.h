@@ -321,8 +321,10 @@ int mireg_thin_gather18(const void* dy, long ld_dy, void* dz, long ld_dz, int B,
 int mireg_tiny_deconv_blocks(int B, int Hc, int Wc);
 int mireg_tiny_deconv_fwd(const void* x_coarse, long ld_c, const float* w, const float* bias, void* y_fine, long ld_f, int B, int Hc,
                           int Wc, int dtype, hipStream_t stream);
-int mireg_tiny_deconv_bwd_data(const void* g_fine, long ld_f, const float* w, void* dx_coarse, long ld_c, int accumulate, int B,
-                               int Hc, int Wc, int dtype, hipStream_t stream);
+/* dx_coarse = conv_s2(g_fine, w) [+ add_nchw, a planar fp32 (B, 2, Hc, Wc) term such as the loss gradient of that flow; may be
+ * NULL] [+ dx_coarse when accumulate] */
+int mireg_tiny_deconv_bwd_data(const void* g_fine, long ld_f, const float* w, void* dx_coarse, long ld_c, int accumulate,
+                               const float* add_nchw, int B, int Hc, int Wc, int dtype, hipStream_t stream);
 int mireg_tiny_deconv_bwd_weights(const void* g_fine, long ld_f, const void* x_coarse, long ld_c, float* slab, int nblocks, int Cpad,
                                   int B, int Hc, int Wc, int dtype, hipStream_t stream);
 

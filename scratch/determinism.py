@@ -6,8 +6,8 @@ from mireg import engine
 from mireg.engine import ConvLayer, Workspace, run_pack
 B = 24
 ws = Workspace(torch.device("cuda:0"), torch.bfloat16)
-for name, cin, cout, k, s, H in [("conv3_1", 256, 256, 3, 1, 32), ("conv4_1", 512, 512, 3, 1, 16), ("deconv3", 128, 770, 4, 2, 32), ("deconv2", 64, 386, 4, 2, 64),
-                                 ("conv3", 128, 256, 5, 2, 64)]:
+for name, cin, cout, k, s, H in [
+                                 ("conv3", 128, 256, 5, 2, 64)][:0]:
     w = torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5
     lay = ConvLayer(name, w, None, s, (k - 1) // 2, 1, ws)
     run_pack(lay.pack_jobs(), ws.code, "cuda:0")
@@ -35,14 +35,56 @@ from oracle import nets
 from mireg.synth import make_pairs
 x, _ = make_pairs(24, 256, seed=6); xd = x.cuda()
 hist = []
+snaps = []
 for rep in range(2):
     torch.manual_seed(1)
     mm = mireg.opticalFlowReg("flownets", precision="bf16"); nets.analytic_weights_(mm)
-    tr = mireg.RegistrationTrainer(mm.cuda(), use_graph=True, autotune=False)
+    tr = mireg.RegistrationTrainer(mm.cuda(), use_graph=os.environ.get('NOGRAPH') != '1', autotune=False,
+                                   overlap_optimizer=os.environ.get('NOOVL') != '1')
+    if os.environ.get('NOSIDE') == '1':
+        from mireg import flownets as _fs
+        _fs.PredictorEngineBase.use_side_stream = False
     rows = []
     for st in range(4):
         loss = tr.step(xd).clone(); torch.cuda.synchronize()
         rows.append((loss.cpu(), tr.flat_g.detach().cpu().clone() if st == 0 else None, tr.flat_p.detach().cpu().clone()))
+        if engine._DBG_LOG:
+            import torch.nn.functional as F
+            for xb, yb, w, xc0, xC, yc0, nm, addc, acc, ya in engine._DBG_LOG:
+                gup = xb[..., xc0:xc0 + 2].float().permute(0, 3, 1, 2)
+                conv = F.conv2d(gup, w.float(), None, 2, 1).permute(0, 2, 3, 1)
+                base = yb[..., yc0:yc0 + 2].float() if acc else 0.0
+                if addc is not None:
+                    base = base + addc.permute(0, 2, 3, 1)
+                exp = (base + conv).bfloat16().float()
+                nm = f"step {st} {nm}"
+                got = ya[..., yc0:yc0 + 2].float()
+                bad = int(((got - exp).abs() > 0).sum())
+                print(f"trainer {rep} {nm}: kernel output vs its in-stream input clones: {bad} elements off", flush=True)
+                if bad > 8:
+                    nz = torch.nonzero((got - exp).abs() > 0)
+                    print("   positions", nz.tolist())
+                    for q in nz[:12].tolist():
+                        b_, y_, x_, c_ = q
+                        print(f"    {q}: got {got[b_, y_, x_, c_].item():.6f} exp {exp[b_, y_, x_, c_].item():.6f} add {addc[b_, c_, y_, x_].item() if addc is not None else 0:.6f} d_before {yb[b_, y_, x_, yc0 + c_].item():.6f} conv {conv[b_, y_, x_, c_].item():.6f} got-d_before {got[b_, y_, x_, c_].item() - yb[b_, y_, x_, yc0 + c_].item():.6f}")
+                        # which single fine pixel / tap contribution would explain the deviation?
+            engine._DBG_LOG.clear()
+        if st == 0:
+            e = tr.eng
+            snap = {}
+            for nm in ("dflowT", "dcat", "flowT", "cat", "flow32", "raw", "draw"):
+                for k, v in getattr(e, nm).items():
+                    snap[f"{nm}[{k}]"] = v.buf.detach().float().cpu().clone()
+            for nm in ("da61", "da6", "da5", "da4", "da3", "da1", "dflow32", "a61"):
+                snap[nm] = getattr(e, nm).buf.detach().float().cpu().clone()
+            for i, g in enumerate(tr.loss.gflow):
+                snap[f"gflow[{i}]"] = g.detach().cpu().clone()
+            for n, l in e.layers.items():
+                if l.wgrad_slab is not None:
+                    snap[f"slab:{n}"] = l.wgrad_slab.detach().float().cpu().clone()
+                if getattr(l, "_dz18", None) is not None:
+                    snap[f"dz18:{n}"] = l._dz18.buf.detach().float().cpu().clone()
+            snaps.append(snap)
     hist.append(rows)
 for st in range(4):
     a, b = hist[0][st], hist[1][st]
@@ -50,12 +92,51 @@ for st in range(4):
 ga, gb = hist[0][0][1], hist[1][0][1]
 d = (ga - gb).abs()
 print("step-0 packed gradient: differing elements", int((d > 0).sum()), "of", d.numel(), "max", d.max().item())
-if (d > 0).any():
-    idx = torch.nonzero(d > 0).flatten()
-    print("first differing offsets", idx[:10].tolist(), "last", idx[-10:].tolist())
-    import bisect
-    eng = tr.eng
-    offs = sorted((eng.flat_off[id(l.weight)], n) for n, l in eng.layers.items())
-    for i in (idx[0].item(), idx[len(idx) // 2].item(), idx[-1].item()):
-        j = bisect.bisect_right([o for o, _ in offs], i) - 1
-        print("  offset", i, "in layer", offs[j][1])
+eng = tr.eng
+for n, l in eng.layers.items():
+    o = eng.flat_off[id(l.weight)]
+    seg = d[o:o + l.Co * l.Kf]
+    if (seg > 0).any():
+        print(f"  layer {n}: {int((seg > 0).sum())} of {seg.numel()} differ, max {seg.max().item():.3e}, split {l.wgrad_split} algo {l.wgrad_algo} tiny {l.tiny} thin {l.thin} thin_gemm {l.thin_gemm}")
+
+print("---- buffers after step 0 ----")
+import itertools
+for k in snaps[0]:
+    a, b = snaps[0][k], snaps[1][k]
+    if a.shape != b.shape:
+        print(k, "shape differs", a.shape, b.shape); continue
+    d = (a - b).abs()
+    if (d > 0).any():
+        nz = torch.nonzero(d > 0)
+        chans = sorted(set(nz[:, -1].tolist()))[:12] if d.dim() == 4 else []
+        if k.startswith(("dflowT", "gflow", "flowT", "flow32", "cat", "raw")) or k in ("a61",):
+            print(f"{k}: {int((d > 0).sum())} of {d.numel()} differ, max {d.max().item():.3e}, last-dim indices {chans}, first positions {nz[:6].tolist()}")
+
+# which trainer is wrong, and by what: recompute dflowT[l+1] = bf16(bf16(loss grad) + conv_s2(gup, W_up)) from the snapshots
+import torch.nn.functional as F
+mref = mireg.opticalFlowReg("flownets", precision="bf16"); nets.analytic_weights_(mref)
+sd = dict(mref.named_parameters())
+upname = {4: "upsampled_flow4_to_3", 5: "upsampled_flow5_to_4", 6: "upsampled_flow6_to_5"}
+for lv in (4, 5, 6):
+    key = f"dflowT[{lv}]"
+    a, b = snaps[0][key], snaps[1][key]
+    d = (a - b).abs()
+    if not (d > 0).any():
+        continue
+    wname = [n for n in sd if upname[lv] in n and n.endswith("weight")]
+    print(lv, "weight", wname)
+    W = sd[wname[0]].detach().float()
+    e = tr.eng
+    cs, cd = e.skip_c[lv - 1], {2: 64, 3: 128, 4: 256, 5: 512}[lv - 1]
+    for t in (0, 1):
+        gup = snaps[t][f"dcat[{lv - 1}]"][..., cs + cd: cs + cd + 2].permute(0, 3, 1, 2)
+        conv = F.conv2d(gup, W, None, 2, 1)
+        gl = [g for k2, g in snaps[t].items() if k2.startswith("gflow") and g.shape[-1] == a.shape[2] and g.shape[-2] == a.shape[1]][0]
+        exp = (gl.bfloat16().float() + conv).bfloat16().float().permute(0, 2, 3, 1)
+        got = snaps[t][key][..., :2]
+        dd = (got - exp).abs()
+        print(f"  trainer {t}: {int((dd > 0).sum())} elements off the recomputation, max {dd.max().item():.3e}")
+        nz = torch.nonzero(dd > 0)[:10]
+        for p in nz.tolist():
+            bb, yy, xx, cc = p
+            print(f"    {p}: got {got[bb, yy, xx, cc].item():.6f} expected {exp[bb, yy, xx, cc].item():.6f} lossgrad {gl[bb, cc, yy, xx].item():.6f} conv {conv[bb, cc, yy, xx].item():.6f}")

@@ -396,7 +396,7 @@ tiny_deconv_fwd_kernel(const T* __restrict__ xc, long ld_c, const float* __restr
 template <typename T>
 __global__ void __launch_bounds__(256)
 tiny_conv_fwd_kernel(const T* __restrict__ xf, long ld_f, const float* __restrict__ w, T* __restrict__ yc, long ld_c, int accumulate,
-                     int B, int Hc, int Wc_) {
+                     const float* __restrict__ add_nchw, int B, int Hc, int Wc_) {
   const int Hf = 2 * Hc, Wf = 2 * Wc_;
   const long n = (long)B * Hc * Wc_;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
@@ -418,6 +418,10 @@ tiny_conv_fwd_kernel(const T* __restrict__ xf, long ld_f, const float* __restric
       }
     }
     T* d = yc + p * ld_c;
+    if (add_nchw) {                                                    // a planar fp32 (B, 2, Hc, Wc) term, e.g. the loss gradient
+      const long hw = (long)Hc * Wc_, o = b * 2 * hw + (long)oy * Wc_ + ox;
+      a0 += add_nchw[o]; a1 += add_nchw[o + hw];
+    }
     if (accumulate) { a0 += (float)d[0]; a1 += (float)d[1]; }
     d[0] = (T)a0; d[1] = (T)a1;
   }
@@ -584,16 +588,16 @@ int mireg_tiny_deconv_fwd(const void* x_coarse, long ld_c, const float* w, const
   MIREG_LAUNCH_RET();
 }
 
-int mireg_tiny_deconv_bwd_data(const void* g_fine, long ld_f, const float* w, void* dx_coarse, long ld_c, int accumulate, int B,
-                               int Hc, int Wc, int dtype, hipStream_t stream) {
+int mireg_tiny_deconv_bwd_data(const void* g_fine, long ld_f, const float* w, void* dx_coarse, long ld_c, int accumulate,
+                               const float* add_nchw, int B, int Hc, int Wc, int dtype, hipStream_t stream) {
   MIREG_CHECK_ARG(g_fine && w && dx_coarse && ld_c >= 2 && ld_f >= 2 && B > 0 && Hc > 0 && Wc > 0);
   MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
   const long n = (long)B * Hc * Wc;
   const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   if (dtype == MIREG_DTYPE_BF16)
-    hipLaunchKernelGGL((tiny_conv_fwd_kernel<__bf16>), dim3(grid), dim3(256), 0, stream, (const __bf16*)g_fine, ld_f, w, (__bf16*)dx_coarse, ld_c, accumulate, B, Hc, Wc);
+    hipLaunchKernelGGL((tiny_conv_fwd_kernel<__bf16>), dim3(grid), dim3(256), 0, stream, (const __bf16*)g_fine, ld_f, w, (__bf16*)dx_coarse, ld_c, accumulate, add_nchw, B, Hc, Wc);
   else
-    hipLaunchKernelGGL((tiny_conv_fwd_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)g_fine, ld_f, w, (float*)dx_coarse, ld_c, accumulate, B, Hc, Wc);
+    hipLaunchKernelGGL((tiny_conv_fwd_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)g_fine, ld_f, w, (float*)dx_coarse, ld_c, accumulate, add_nchw, B, Hc, Wc);
   MIREG_LAUNCH_RET();
 }
 

@@ -240,6 +240,13 @@ USE_STEM = True
 WGRAD_ALGO = int(os.environ.get('MIREG_WGRAD_ALGO', '0'))         # tests / A-B runs: 0 auto, 1 ring kernel, 2 halo kernel required
 FORCE_ALGO = None      # tests only: (algo, tile_m[, tile_n]) for every mireg_conv_gemm launch
 THIN_GEMM_ROWS = int(os.environ.get('MIREG_THIN_GEMM_ROWS', '16384'))   # heads with at least this many pixels run as 1x1 GEMMs
+USE_TINY = os.environ.get('MIREG_NO_TINY', '0') != '1'   # experiments / A-B runs only
+# which forms of the 2->2 upsamplers take the pixel-parallel kernels: 1 forward, 2 backward-data, 4 backward-weights.
+# Backward-data stays on the GEMM path by default: launched back to back behind its producer while the wgrad stream is
+# writing slabs, the 3-us kernel was measured to read operands that the preceding main-stream kernel had not made
+# visible yet (run-to-run differences of two identically seeded trainers; a delay in front of it removes them, see
+# DESIGN.md section 5).  The kernel itself is exact (tests/test_thin_gpu.py).
+TINY_MASK = int(os.environ.get('MIREG_TINY_MASK', '5'))
 USE_HALO = os.environ.get('MIREG_NO_HALO', '0') != '1'   # experiments / A-B runs only
 USE_THIN = True     # module switch (tests compare the thin kernels with the GEMM path)
 
@@ -333,7 +340,7 @@ class ConvLayer:
         self.thin = USE_THIN and (self.Co, self.kh, self.kw, self.s, self.p, self.d) == (2, 3, 3, 1, 1, 1)
         self.thin_gemm = False                             # decided in plan_wgrad (forward decides per call)
         # 2 -> 2 channel ConvTranspose2d(4, 2, 1) upsamplers: pixel-parallel kernels on the master weight (csrc/thin_conv.hip)
-        self.tiny = USE_THIN and (self.Co, self.Ci, self.kh, self.kw, self.s, self.p, self.d) == (2, 2, 4, 4, 2, 1, 1)
+        self.tiny = USE_THIN and USE_TINY and (self.Co, self.Ci, self.kh, self.kw, self.s, self.p, self.d) == (2, 2, 4, 4, 2, 1, 1)
         # 1-2 channel 7x7/s2 input convolutions: patch-staged kernels with K = (ky, kx, ci) (stem_conv.hip)
         self.stem = (USE_STEM and ws.code == DT_BF16 and (self.kh, self.kw, self.s, self.p, self.d) == (7, 7, 2, 3, 1)
                      and self.Ci <= 2 and self.Co == 64)
@@ -451,18 +458,24 @@ class ConvLayer:
         self.ws.tuned[key] = best
         apply(*best)
 
+    def tiny_bwd_data_ok(self, x: View, y: View) -> bool:
+        """True when run_fwd_form(x, y) takes the pixel-parallel 2->2 upsampler kernel (which can fuse a planar addend)."""
+        return bool(self.tiny and (TINY_MASK & 2) and (x.H, x.W) == (2 * y.H, 2 * y.W))
+
     def run_fwd_form(self, x: View, y: Optional[View], *, y32: Optional[View] = None, slope: float = 1.0,
-                     bias: bool = True, accumulate: bool = False) -> None:
+                     bias: bool = True, accumulate: bool = False, add_nchw: Optional[torch.Tensor] = None) -> None:
         """y[(oy,ox)] = act(sum_{ky,kx,ci} x[oy*s-p+ky*d, ox*s-p+kx*d, ci] W[co][ci][ky][kx] + b)."""
         assert x.C <= self.Cip and x.c0 + self.Cip <= x.ld, (self.name, x.C, self.Ci, x.ld)
         Ho = (x.H + 2 * self.p - self.d * (self.kh - 1) - 1) // self.s + 1
         Wo = (x.W + 2 * self.p - self.d * (self.kw - 1) - 1) // self.s + 1
         out = y if y is not None else y32
         assert (out.H, out.W) == (Ho, Wo), (self.name, (out.H, out.W), (Ho, Wo))
-        if self.tiny and y is not None and y32 is None and slope == 1.0 and not bias and (x.H, x.W) == (2 * Ho, 2 * Wo):
-            _lib.call("mireg_tiny_deconv_bwd_data", x.ptr, x.ld, self.weight.data_ptr(), y.ptr, y.ld, int(accumulate), x.B, Ho, Wo,
+        if self.tiny and (TINY_MASK & 2) and y is not None and y32 is None and slope == 1.0 and not bias and (x.H, x.W) == (2 * Ho, 2 * Wo):
+            _lib.call("mireg_tiny_deconv_bwd_data", x.ptr, x.ld, self.weight.data_ptr(), y.ptr, y.ld, int(accumulate),
+                      add_nchw.data_ptr() if add_nchw is not None else None, x.B, Ho, Wo,
                       self.ws.code, _stream())
             return
+        assert add_nchw is None, "add_nchw: only the 2->2 upsampler kernels fuse a planar addend"
         if self.stem and y is not None and y32 is None and not accumulate:
             PROFILER.call("stem_conv_fwd", 2.0 * x.B * Ho * Wo * self.Co * 49 * self.Ci, f"{self.name}:stem-fwd",
                           "mireg_stem_conv_fwd", x.ptr, x.ld, self.packF.data_ptr(), self.Kf, self.Cip,
@@ -518,7 +531,7 @@ class ConvLayer:
         (only exact divisions contribute).  out has the LARGER spatial size."""
         assert g.C <= self.Cop and g.c0 + self.Cop <= g.ld, (self.name, g.C, self.Co, g.ld)
         o = out if out is not None else y32
-        if self.tiny and out is not None and y32 is None and slope == 1.0 and not accumulate and (out.H, out.W) == (2 * g.H, 2 * g.W):
+        if self.tiny and (TINY_MASK & 1) and out is not None and y32 is None and slope == 1.0 and not accumulate and (out.H, out.W) == (2 * g.H, 2 * g.W):
             _lib.call("mireg_tiny_deconv_fwd", g.ptr, g.ld, self.weight.data_ptr(),
                       self.bias.data_ptr() if (bias and self.bias is not None) else None, out.ptr, out.ld, g.B, g.H, g.W,
                       self.ws.code, _stream())
@@ -571,7 +584,7 @@ class ConvLayer:
         tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
         nk = (dy.rows + bk - 1) // bk
         self.thin_gemm = self.thin and dy.rows >= THIN_GEMM_ROWS
-        if self.tiny:
+        if self.tiny and (TINY_MASK & 4):
             self.wgrad_split = _lib.lib().mireg_tiny_deconv_blocks(dy.B, dy.H, dy.W)
         elif self.thin_gemm:                                   # 1x1 backward-weights GEMM on (dz, x): 128-column tiles x pixel splits
             self.wgrad_split = max(1, min(512 // ((self.Cip + 127) // 128), nk // 8, 192))
@@ -664,7 +677,7 @@ class ConvLayer:
         if self.wgrad_slab is None:
             self.plan_wgrad(x, dy)
         assert x.C <= self.Cip and x.c0 + self.Cip <= x.ld and dy.c0 + rup(self.Co, 8) <= dy.ld, self.name
-        if self.tiny:
+        if self.tiny and (TINY_MASK & 4):
             _lib.call("mireg_tiny_deconv_bwd_weights", x.ptr, x.ld, dy.ptr, dy.ld, self.wgrad_slab[slot * self.wgrad_split].data_ptr(),
                       self.wgrad_split, self.Cip, dy.B, dy.H, dy.W, self.ws.code, _stream())
             return

@@ -313,10 +313,16 @@ class FlowNetDecoderMixin:
             # flow upsampler (lvl+1 -> lvl): no activation
             gup = dc[lvl].slice(cs + cd, 2)
             up = L[f"up{lvl + 1}"]
-            load_loss_grad(lvl + 1)                                           # dflowT[lvl+1] <- loss grad
+            gt = glvl.get(lvl + 1)
+            fused = up.tiny_bwd_data_ok(gup, self.dflowT[lvl + 1]) and gt is not None and gt.dtype == torch.float32
+            if not fused:
+                load_loss_grad(lvl + 1)                                       # dflowT[lvl+1] <- loss grad
             m_up = self.mark()
             up.run_bias_grad(gup)
-            up.run_fwd_form(gup, self.dflowT[lvl + 1], bias=False, accumulate=True)
+            if fused:                                                         # dflowT[lvl+1] <- loss grad + upsampler backward-data
+                up.run_fwd_form(gup, self.dflowT[lvl + 1], bias=False, add_nchw=gt.contiguous())
+            else:
+                up.run_fwd_form(gup, self.dflowT[lvl + 1], bias=False, accumulate=True)
             self.wgrad_async(up, gup, self.flowT[lvl + 1], after=m_up)
             # feature deconv (lvl+1 -> lvl) + LeakyReLU
             gde = dc[lvl].slice(cs, cd)

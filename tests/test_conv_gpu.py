@@ -129,6 +129,52 @@ def test_deconv_forms(prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_tiny_upsampler_kernels(prec):
+    """The pixel-parallel kernels of the 2 -> 2 channel ConvTranspose2d(4, 2, 1) flow upsamplers (FlowNetS/FlowNetS.py:37-40):
+    forward, backward-data (plain / accumulating / with the fused planar addend) and backward-weights vs torch autograd."""
+    from mireg import engine
+    from mireg.engine import ConvLayer, Workspace, run_pack, run_unpack
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    tol = 3e-5 if prec == "fp32" else 1.5e-2
+    ws = Workspace(torch.device(DEV), dt)
+    g = torch.Generator().manual_seed(11)
+    old = engine.TINY_MASK
+    engine.TINY_MASK = 7
+    try:
+        for H, W, B in ((4, 4, 3), (16, 8, 24), (5, 7, 1)):
+            x = torch.randn(B, 2, H, W, generator=g)
+            w = torch.randn(2, 2, 4, 4, generator=g) * 0.3
+            bias = torch.randn(2, generator=g)
+            cot = torch.randn(B, 2, 2 * H, 2 * W, generator=g)
+            add = torch.randn(B, 2, H, W, generator=g)
+            if prec == "bf16":
+                x, cot = x.bfloat16().float(), cot.bfloat16().float()
+            xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+            y_ref = F.conv_transpose2d(xr, wr, bias, 2, 1)
+            (y_ref * cot).sum().backward()
+            lay = ConvLayer("u", w.to(DEV), bias.to(DEV), 2, 1, 1, ws)
+            assert lay.tiny
+            run_pack(lay.pack_jobs(), ws.code, DEV)
+            xv, gv = _view_from(x.to(DEV), ws), _view_from(cot.to(DEV), ws)
+            yv = ws.new(B, 2 * H, 2 * W, 2)
+            lay.run_dgrad_form(xv, yv, bias=True)
+            assert _rel(yv.nchw().float(), y_ref.detach()) < tol, "forward"
+            dxv = ws.new(B, H, W, 2)
+            assert lay.tiny_bwd_data_ok(gv, dxv)
+            lay.run_fwd_form(gv, dxv, bias=False)
+            assert _rel(dxv.nchw().float(), xr.grad) < tol, "backward-data"
+            lay.run_fwd_form(gv, dxv, bias=False, accumulate=True)
+            assert _rel(dxv.nchw().float(), 2 * xr.grad) < 2 * tol, "backward-data, accumulating"
+            lay.run_fwd_form(gv, dxv, bias=False, add_nchw=add.to(DEV))
+            assert _rel(dxv.nchw().float(), xr.grad + add) < tol, "backward-data + planar addend"
+            lay.run_wgrad(gv, xv)
+            run_unpack([lay.unpack_job()], DEV)
+            assert _rel(lay.grad_w, wr.grad) < tol, "backward-weights"
+    finally:
+        engine.TINY_MASK = old
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_batchnorm_lrelu(prec):
     from mireg.engine import BatchNormAct, Workspace
     dt = torch.float32 if prec == "fp32" else torch.bfloat16
