@@ -151,6 +151,198 @@ class FlowNetC(nn.Module, _FlowNetDecoderMixin):
         return (fl[2],)
 
 
+# FlowNet2 stack ----------------------------------
+def _i_conv(bn: bool, cin: int, cout: int) -> nn.Sequential:
+    """flownet2/networks/submodules.py:20-30: conv (bias on) [+ BatchNorm], no activation."""
+    layers: List[nn.Module] = [nn.Conv2d(cin, cout, 3, 1, 1, bias=True)]
+    if bn:
+        layers.append(nn.BatchNorm2d(cout))
+    return nn.Sequential(*layers)
+
+
+def _deconv(cin: int, cout: int) -> nn.Sequential:
+    """flownet2/networks/submodules.py:35-39."""
+    return nn.Sequential(nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
+
+
+def _xavier_(mod: nn.Module) -> None:
+    """flownet2/networks/FlowNetSD.py:52-61 (same loop in FlowNetS / FlowNetFusion / FlowNet2)."""
+    for m in mod.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            if m.bias is not None:
+                nn.init.uniform_(m.bias)
+            nn.init.xavier_uniform_(m.weight)
+
+
+class FlowNet2S(nn.Module, _FlowNetDecoderMixin):
+    """flownet2/networks/FlowNetS.py:13-94: the FlowNetS of the FlowNet2 stack -- `input_channels` inputs (6 inside
+    FlowNet2), biases on for deconv / predict_flow, off for the flow upsamplers, no 256x256 top flow."""
+
+    def __init__(self, args=None, input_channels: int = 6, batchNorm: bool = True):
+        super().__init__()
+        self.batchNorm = batchNorm
+        for name, cin, cout, k, s in FLOWNETS_ENCODER:
+            setattr(self, name, _conv_block(batchNorm, input_channels if name == "conv1" else cin, cout, k, s))
+        self._build_decoder(bias=True)
+        for lvl in (6, 5, 4, 3):
+            setattr(self, f"upsampled_flow{lvl}_to_{lvl - 1}", nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=False))
+        _xavier_(self)
+
+    def forward(self, x):
+        c2 = self.conv2(self.conv1(x))
+        c3 = self.conv3_1(self.conv3(c2))
+        c4 = self.conv4_1(self.conv4(c3))
+        c5 = self.conv5_1(self.conv5(c4))
+        c6 = self.conv6_1(self.conv6(c5))
+        fl = self._decode({6: c6, 5: c5, 4: c4, 3: c3, 2: c2})
+        if self.training:
+            return fl[2], fl[3], fl[4], fl[5], fl[6]
+        return (fl[2],)
+
+
+# (name, cin, cout, stride), all 3x3 -- flownet2/networks/FlowNetSD.py:17-29
+FLOWNETSD_ENCODER = [("conv0", 2, 64, 1), ("conv1", 64, 64, 2), ("conv1_1", 64, 128, 1), ("conv2", 128, 128, 2),
+                     ("conv2_1", 128, 128, 1), ("conv3", 128, 256, 2), ("conv3_1", 256, 256, 1), ("conv4", 256, 512, 2),
+                     ("conv4_1", 512, 512, 1), ("conv5", 512, 512, 2), ("conv5_1", 512, 512, 1), ("conv6", 512, 1024, 2),
+                     ("conv6_1", 1024, 1024, 1)]
+FLOWNETSD_INTER = {5: (1026, 512), 4: (770, 256), 3: (386, 128), 2: (194, 64)}     # FlowNetSD.py:36-39
+FLOWNETSD_PREDICT = {6: 1024, 5: 512, 4: 256, 3: 128, 2: 64}                       # FlowNetSD.py:41-45
+
+
+class FlowNetSD(nn.Module):
+    """flownet2/networks/FlowNetSD.py:13-106: small-displacement net, all-3x3 encoder from full resolution, an
+    `inter_conv` (no activation) between every concat and its flow head, biases on everywhere in the decoder."""
+
+    def __init__(self, args=None, batchNorm: bool = True):
+        super().__init__()
+        self.batchNorm = batchNorm
+        for name, cin, cout, s in FLOWNETSD_ENCODER:
+            setattr(self, name, _conv_block(batchNorm, cin, cout, 3, s))
+        for lvl, (cin, cout) in FLOWNET_DECODER.items():
+            setattr(self, f"deconv{lvl}", _deconv(cin, cout))
+        for lvl, (cin, cout) in FLOWNETSD_INTER.items():
+            setattr(self, f"inter_conv{lvl}", _i_conv(batchNorm, cin, cout))
+        for lvl, cin in FLOWNETSD_PREDICT.items():
+            setattr(self, f"predict_flow{lvl}", nn.Conv2d(cin, 2, 3, 1, 1, bias=True))
+        for lvl in (6, 5, 4, 3):
+            setattr(self, f"upsampled_flow{lvl}_to_{lvl - 1}", nn.ConvTranspose2d(2, 2, 4, 2, 1))
+        _xavier_(self)
+
+    def forward(self, x):
+        c1 = self.conv1_1(self.conv1(self.conv0(x)))
+        skips = {2: self.conv2_1(self.conv2(c1))}
+        for lvl in (3, 4, 5, 6):
+            skips[lvl] = getattr(self, f"conv{lvl}_1")(getattr(self, f"conv{lvl}")(skips[lvl - 1]))
+        flows = {6: self.predict_flow6(skips[6])}
+        feat = skips[6]
+        for lvl in (5, 4, 3, 2):
+            up = getattr(self, f"upsampled_flow{lvl + 1}_to_{lvl}")(flows[lvl + 1])
+            dec = getattr(self, f"deconv{lvl}")(feat)
+            feat = torch.cat((skips[lvl], dec, up), 1)
+            flows[lvl] = getattr(self, f"predict_flow{lvl}")(getattr(self, f"inter_conv{lvl}")(feat))
+        if self.training:
+            return flows[2], flows[3], flows[4], flows[5], flows[6]
+        return (flows[2],)
+
+
+class FlowNetFusion(nn.Module):
+    """flownet2/networks/FlowNetFusion.py:12-67: 9 input channels at full resolution, two strided levels, flow0 out."""
+
+    def __init__(self, args=None, batchNorm: bool = True):
+        super().__init__()
+        self.batchNorm = batchNorm
+        self.conv0 = _conv_block(batchNorm, 9, 64)
+        self.conv1 = _conv_block(batchNorm, 64, 64, 3, 2)
+        self.conv1_1 = _conv_block(batchNorm, 64, 128)
+        self.conv2 = _conv_block(batchNorm, 128, 128, 3, 2)
+        self.conv2_1 = _conv_block(batchNorm, 128, 128)
+        self.deconv1 = _deconv(128, 32)
+        self.deconv0 = _deconv(162, 16)
+        self.inter_conv1 = _i_conv(batchNorm, 162, 32)
+        self.inter_conv0 = _i_conv(batchNorm, 82, 16)
+        self.predict_flow2 = nn.Conv2d(128, 2, 3, 1, 1, bias=True)
+        self.predict_flow1 = nn.Conv2d(32, 2, 3, 1, 1, bias=True)
+        self.predict_flow0 = nn.Conv2d(16, 2, 3, 1, 1, bias=True)
+        self.upsampled_flow2_to_1 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        self.upsampled_flow1_to_0 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        _xavier_(self)
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c1 = self.conv1_1(self.conv1(c0))
+        c2 = self.conv2_1(self.conv2(c1))
+        flow2 = self.predict_flow2(c2)
+        cat1 = torch.cat((c1, self.deconv1(c2), self.upsampled_flow2_to_1(flow2)), 1)
+        flow1 = self.predict_flow1(self.inter_conv1(cat1))
+        cat0 = torch.cat((c0, self.deconv0(cat1), self.upsampled_flow1_to_0(flow1)), 1)
+        return self.predict_flow0(self.inter_conv0(cat0))
+
+
+class Resample2d(nn.Module):
+    """Stand-in for the external resample2d_package (see ops.resample2d; parity unpinned)."""
+
+    def forward(self, src, flow):
+        return ops.resample2d(src, flow)
+
+
+class ChannelNorm(nn.Module):
+    """Stand-in for the external channelnorm_package (see ops.channelnorm; parity unpinned)."""
+
+    def forward(self, x):
+        return ops.channelnorm(x)
+
+
+class FlowNet2(nn.Module):
+    """flownet2/models.py:30-191 as the reference instantiates it (models.py:225, batchNorm=True): FlowNetC -> FlowNetS ->
+    FlowNetS on [images, warped image, flow / div_flow, brightness error], FlowNetSD beside them, FlowNetFusion on top.
+    The rgb-mean normalisation is commented out in the reference's forward (models.py:122-126): inputs go in as they are."""
+
+    def __init__(self, args=None, batchNorm: bool = False, div_flow: float = 20.0):
+        super().__init__()
+        self.batchNorm, self.div_flow = batchNorm, div_flow
+        self.channelnorm = ChannelNorm()
+        self.flownetc = FlowNetC(args, batchNorm=batchNorm)
+        self.upsample1 = nn.Upsample(scale_factor=4, mode="bilinear")
+        self.resample1 = Resample2d()
+        self.flownets_1 = FlowNet2S(args, batchNorm=batchNorm)
+        self.upsample2 = nn.Upsample(scale_factor=4, mode="bilinear")
+        self.resample2 = Resample2d()
+        self.flownets_2 = FlowNet2S(args, batchNorm=batchNorm)
+        self.flownets_d = FlowNetSD(args, batchNorm=batchNorm)
+        self.upsample3 = nn.Upsample(scale_factor=4, mode="nearest")
+        self.upsample4 = nn.Upsample(scale_factor=4, mode="nearest")
+        self.resample3 = Resample2d()
+        self.resample4 = Resample2d()
+        self.flownetfusion = FlowNetFusion(args, batchNorm=batchNorm)
+        _xavier_(self)
+
+    def stages(self, inputs):
+        """All intermediate flows, for the fixtures: (flownetc_flow2, flownets1_flow2, flownets2_flow2, flownetsd_flow2, fused)."""
+        x1, x2 = inputs[:, 0:1], inputs[:, 1:2]
+        c2 = self.flownetc(inputs)[0]
+        cflow = self.upsample1(c2 * self.div_flow)
+        r1 = self.resample1(x2, cflow)
+        cat1 = torch.cat((inputs, r1, cflow / self.div_flow, self.channelnorm(x1 - r1)), 1)
+        s1 = self.flownets_1(cat1)[0]
+        s1flow = self.upsample2(s1 * self.div_flow)
+        r2 = self.resample2(x2, s1flow)
+        cat2 = torch.cat((inputs, r2, s1flow / self.div_flow, self.channelnorm(x1 - r2)), 1)
+        s2 = self.flownets_2(cat2)[0]
+        s2flow = self.upsample4(s2 * self.div_flow)
+        n_s2 = self.channelnorm(s2flow)
+        d_s2 = self.channelnorm(x1 - self.resample4(x2, s2flow))
+        sd = self.flownets_d(inputs)[0]
+        sdflow = self.upsample3(sd / self.div_flow)
+        n_sd = self.channelnorm(sdflow)
+        d_sd = self.channelnorm(x1 - self.resample3(x2, sdflow))
+        cat3 = torch.cat((x1, sdflow, s2flow, n_sd, n_s2, d_sd, d_s2), 1)
+        return c2, s1, s2, sd, self.flownetfusion(cat3)
+
+    def forward(self, inputs):
+        fused = self.stages(inputs)[-1]
+        return fused, fused
+
+
 # PWC-DC-Net -----------------------------------------------------------------
 PWC_PYRAMID = [(1, 16), (16, 32), (32, 64), (64, 96), (96, 128), (128, 196)]  # PWCNet.py:50-67
 PWC_DENSE = [128, 128, 96, 64, 32]                                            # PWCNet.py:73-80

@@ -1,0 +1,20 @@
+"""The cost-volume kernels alone at the benchmarked sizes (for rocprofv3 --pmc / --kernel-trace passes):
+FlowNetC B=24, 256 ch, 32x32, md 20 / stride2 2 (441 ch) and PWC level 2 B=48, 32 ch, 64x64, md 4 (81 ch); bf16, 12 launches each."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mireg
+from mireg.engine import Workspace, DT_BF16
+from mireg.correlation import correlation_views, correlation_bwd_views
+ws = Workspace(torch.device("cuda:0"), torch.bfloat16)
+for B, C, H, md, s2 in ((24, 256, 32, 20, 2), (48, 32, 64, 4, 1), (48, 196, 4, 4, 1)):
+    D = 2 * (md // s2) + 1
+    f1, f2 = ws.new(B, H, H, C), ws.new(B, H, H, C)
+    f1.buf.normal_(); f2.buf.normal_()
+    out, g = ws.new(B, H, H, D * D), ws.new(B, H, H, D * D)
+    g.buf.normal_()
+    d1, d2 = ws.new(B, H, H, C), ws.new(B, H, H, C)
+    for _ in range(12):
+        correlation_views(f1, f2, out, C, md, s2, 0.1, DT_BF16)
+        correlation_bwd_views(g, f1, f2, d1, d2, (C + 7) // 8 * 8, C, md, s2, 0, 0, DT_BF16)
+    torch.cuda.synchronize()
+print("done")

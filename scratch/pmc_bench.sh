@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$TAG
 timeout -k 10 200 python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-3d --no-other-models --tune-cache $R/gpurun_out/$TAG/tune.json > /dev/null 2>&1
-timeout -k 10 400 rocprofv3 --pmc $CNT --output-format csv -d $R/gpurun_out/$TAG/pmc -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-3d --no-graph --tune-cache $R/gpurun_out/$TAG/tune.json > $R/gpurun_out/$TAG/out.txt 2> $R/gpurun_out/$TAG/err.txt
+timeout -k 10 400 rocprofv3 --pmc $CNT --output-format csv -d $R/gpurun_out/$TAG/pmc -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-3d --no-other-models --no-graph --tune-cache $R/gpurun_out/$TAG/tune.json > $R/gpurun_out/$TAG/out.txt 2> $R/gpurun_out/$TAG/err.txt
 F=$(find $R/gpurun_out/$TAG/pmc -name "*counter_collection.csv" | head -1)
 python3 - "$F" "$PAT" $R/gpurun_out/$TAG/summary.json <<'PY'
 import csv, sys, collections, json, hashlib, os

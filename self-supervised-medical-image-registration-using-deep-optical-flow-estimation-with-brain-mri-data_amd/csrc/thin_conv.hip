@@ -506,7 +506,10 @@ int mireg_thin_conv_dgrad(const void* dy, long ld_dy, const void* w, long ld_w, 
   const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
   const long total = (long)B * H * W * (Cpad / V);
   const size_t lds = (size_t)CO * TAPS * Cpad * (dtype == MIREG_DTYPE_BF16 ? 2 : 4);
-  const int grid = (int)((total + 255) / 256 < 768 ? (total + 255) / 256 : 768);
+  // latency-bound (nine dependent dy loads per item): as many resident blocks per CU as the weight tile in LDS allows
+  const long per_cu = lds + 1024 > 160 * 1024 / 8 ? (long)(160 * 1024 / (lds + 1024)) : 8;
+  const long cap = 256 * (per_cu < 1 ? 1 : per_cu);
+  const int grid = (int)((total + 255) / 256 < cap ? (total + 255) / 256 : cap);
   if (dtype == MIREG_DTYPE_BF16) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)thin_dgrad_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((thin_dgrad_kernel<__bf16>), dim3(grid), dim3(256), lds, stream, a);
@@ -571,8 +574,8 @@ int mireg_thin_gather18(const void* dy, long ld_dy, void* dz, long ld_dz, int B,
 
 int mireg_tiny_deconv_blocks(int B, int Hc, int Wc) {
   const long n = (long)B * Hc * Wc;
-  const long g = (n + 1023) / 1024;
-  return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));
+  const long g = (n + 255) / 256;                      // one coarse pixel per thread: the kernel is a chain of dependent gathers,
+  return (int)(g < 1 ? 1 : (g > 192 ? 192 : g));       // so it wants blocks, not work per block (slab: 1 KiB per block)
 }
 
 int mireg_tiny_deconv_fwd(const void* x_coarse, long ld_c, const float* w, const float* bias, void* y_fine, long ld_f, int B, int Hc,

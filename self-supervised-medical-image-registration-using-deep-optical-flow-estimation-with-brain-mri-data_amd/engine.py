@@ -239,7 +239,7 @@ FORCE_TILE_N = int(os.environ.get('MIREG_TILE_N', '0'))   # experiments only
 USE_STEM = True
 WGRAD_ALGO = int(os.environ.get('MIREG_WGRAD_ALGO', '0'))         # tests / A-B runs: 0 auto, 1 ring kernel, 2 halo kernel required
 FORCE_ALGO = None      # tests only: (algo, tile_m[, tile_n]) for every mireg_conv_gemm launch
-THIN_GEMM_ROWS = int(os.environ.get('MIREG_THIN_GEMM_ROWS', '16384'))   # heads with at least this many pixels run as 1x1 GEMMs
+THIN_GEMM_ROWS = int(os.environ.get('MIREG_THIN_GEMM_ROWS', '1024'))   # heads with at least this many pixels run as 1x1 GEMMs
 USE_TINY = os.environ.get('MIREG_NO_TINY', '0') != '1'   # experiments / A-B runs only
 # which forms of the 2->2 upsamplers take the pixel-parallel kernels: 1 forward, 2 backward-data, 4 backward-weights.
 # Backward-data stays on the GEMM path by default: launched back to back behind its producer while the wgrad stream is
