@@ -70,8 +70,8 @@ def import_reference():
                 "flownet2.networks.channelnorm_package"):
         _placeholder(pkg)
     _placeholder("flownet2.networks.correlation_package.correlation", **corr_mod)
-    _placeholder("flownet2.networks.resample2d_package.resample2d", Resample2d=None)
-    _placeholder("flownet2.networks.channelnorm_package.channelnorm", ChannelNorm=None)
+    _placeholder("flownet2.networks.resample2d_package.resample2d", Resample2d=nets.Resample2d)
+    _placeholder("flownet2.networks.channelnorm_package.channelnorm", ChannelNorm=nets.ChannelNorm)
     ref = types.SimpleNamespace()
     ref.FlowNetS = importlib.import_module("FlowNetS.FlowNetS").FlowNetS
     ref.loss = importlib.import_module("loss")
@@ -81,6 +81,7 @@ def import_reference():
     ref.models.device = torch.device("cpu")
     ref.FlowNetC = importlib.import_module("flownet2.networks.FlowNetC").FlowNetC
     ref.pwc = importlib.import_module("PWC.models.PWCNet")
+    ref.flownet2 = importlib.import_module("flownet2.models")
     return ref
 
 
@@ -344,12 +345,52 @@ def g8_adam(ref):
     save("g8_adam", p0=tp[0].detach().numpy(), p1=tp[1].detach().numpy())
 
 
+def g9_flownet2(ref):
+    print("G9 FlowNet2 stack (reference flownet2/models.py:30-191 + networks/FlowNetS|SD|Fusion.py, oracle Correlation / "
+          "Resample2d / ChannelNorm injected for the absent custom layers)")
+    args = types.SimpleNamespace(fp16=False, rgb_max=255.0)
+    out = {}
+    # the two new sub-networks on their own, train-mode BatchNorm and eval
+    for cls_name, shape, seed in (("FlowNetSD", (2, 2, 64, 64), 21), ("FlowNetFusion", (2, 9, 64, 64), 22), ("FlowNetS", (2, 6, 64, 64), 23)):
+        mod = importlib.import_module(f"flownet2.networks.{cls_name}")
+        r = getattr(mod, cls_name)(args, batchNorm=True)
+        o = {"FlowNetSD": nets.FlowNetSD, "FlowNetFusion": nets.FlowNetFusion, "FlowNetS": nets.FlowNet2S}[cls_name](args, batchNorm=True)
+        nets.analytic_weights_(r)
+        o.load_state_dict(r.state_dict())
+        x = nets.analytic_input(shape, seed=seed, lo=-1.0, hi=1.0)
+        for mode in ("train", "eval"):
+            r.train(mode == "train"); o.train(mode == "train")
+            with torch.no_grad():
+                fr, fo = r(x), o(x)
+            fr, fo = (fr, fo) if isinstance(fr, tuple) else ((fr,), (fo,))
+            assert len(fr) == len(fo)
+            for i, (a, b) in enumerate(zip(fo, fr)):
+                close(a, b, 5e-5, f"{cls_name} {mode} out{i}")
+                out[f"{cls_name.lower()}_{mode}_{i}"] = b.numpy()
+    # the whole stack as models.py:225 builds it
+    r = ref.flownet2.FlowNet2(args, batchNorm=True)
+    o = nets.FlowNet2(args, batchNorm=True)
+    nets.analytic_weights_(r)
+    o.load_state_dict(r.state_dict())
+    x = nets.analytic_input((1, 2, 256, 256), seed=24)
+    r.eval(); o.eval()
+    with torch.no_grad():
+        fr = r(x)
+        st = o.stages(x)
+    assert len(fr) == 2 and torch.equal(fr[0], fr[1])
+    close(st[-1], fr[0], 5e-4, "FlowNet2 fused flow")
+    for name, t in zip(("flownetc_flow2", "flownets1_flow2", "flownets2_flow2", "flownetsd_flow2"), st[:4]):
+        out[f"flownet2_{name}"] = t.numpy()
+    out["flownet2_fused"] = fr[0].numpy()[:, :, ::2, ::2]
+    save("g9_flownet2", **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = import_reference()
     only = set(sys.argv[1:])
-    for fn in (g1_flownets, g2_stn, g3_losses, g4_dice, g5_skeletons, g6_pwc_warp, g7_affine3d, g8_adam):
+    for fn in (g1_flownets, g2_stn, g3_losses, g4_dice, g5_skeletons, g6_pwc_warp, g7_affine3d, g8_adam, g9_flownet2):
         if not only or fn.__name__.split("_")[0] in only:
             fn(ref)
     print("all restatement-vs-reference checks passed")

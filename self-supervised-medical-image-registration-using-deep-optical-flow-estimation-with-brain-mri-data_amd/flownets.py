@@ -375,7 +375,8 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
         self.hs = hs
         self.setup_decoder(m)
         new = ws.new
-        self.x8 = new(B, H, W, 2)
+        self.cin = m.conv1[0].in_channels                    # 2 (FlowNetS/FlowNetS.py:17), 6 inside the FlowNet2 stack
+        self.x8 = new(B, H, W, self.cin)
         self.a1 = new(B, *hs[1], 64)
         self.cat = {2: new(B, *hs[2], 194), 3: new(B, *hs[3], 386), 4: new(B, *hs[4], 770), 5: new(B, *hs[5], 1026)}
         self.skip_c = {2: 128, 3: 256, 4: 512, 5: 512}
@@ -400,7 +401,7 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
         self.training_cache = training
         self.pack_weights()
         x = x.contiguous()
-        nchw_to_view(x, 0, 2, self.x8)
+        nchw_to_view(x, 0, self.cin, self.x8)
         for name, *_ in ENCODER:
             src, dst = self.enc_io[name]
             if self.bn:

@@ -37,11 +37,14 @@ class opticalFlowReg(nn.Module):
     def __init__(self, conv_predictor: str = "flownets", precision: str = "bf16", pretrained: Optional[str] = None):
         super().__init__()
         name = conv_predictor.lower()
-        if "flownet2" in name or "raft" in name:
+        if "raft" in name:
             raise NotImplementedError(
                 f"predictor '{conv_predictor}' is outside the accelerated hot path (SURVEY section 8f); "
-                "available: 'flownets' (default), 'flownetc', 'pwc'")
-        if "pwc" in name:
+                "available: 'flownets' (default), 'flownetc', 'pwc', 'flownet2' (inference)")
+        if "flownet2" in name:                              # reference models.py:212-225: FlowNet2(args, batchNorm=True)
+            from .flownet2 import FlowNet2
+            self.predictor = FlowNet2(None, batchNorm=True, precision=precision)
+        elif "pwc" in name:
             from .pwcnet import PWCDCNet
             self.predictor = PWCDCNet(md=4, precision=precision)
         elif "flownetc" in name:

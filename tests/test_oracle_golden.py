@@ -133,3 +133,31 @@ def test_affine3d_and_adam(golden):
         ops.adam_step(p, [x * step for x in gr], m, v, step)
     _close(p[0], g["p0"], 1e-6)
     _close(p[1], g["p1"], 1e-6)
+
+
+def test_flownet2_stack(golden):
+    """G9: the FlowNet2 stack of flownet2/models.py:30-191 (reference classes run with the oracle's Correlation / Resample2d /
+    ChannelNorm injected for the absent custom layers): the two new sub-networks and the 6-channel FlowNetS in train and eval
+    mode, and the whole chain's intermediate and fused flows."""
+    g = golden("g9_flownet2")
+    for cls, key, shape, seed in ((nets.FlowNetSD, "flownetsd", (2, 2, 64, 64), 21), (nets.FlowNetFusion, "flownetfusion", (2, 9, 64, 64), 22),
+                                  (nets.FlowNet2S, "flownets", (2, 6, 64, 64), 23)):
+        m = cls(None, batchNorm=True)
+        nets.analytic_weights_(m)
+        x = nets.analytic_input(shape, seed=seed, lo=-1.0, hi=1.0)
+        for mode in ("train", "eval"):
+            m.train(mode == "train")
+            with torch.no_grad():
+                out = m(x)
+            out = out if isinstance(out, tuple) else (out,)
+            assert len(out) == sum(k.startswith(f"{key}_{mode}_") for k in g.files)
+            for i, o in enumerate(out):
+                _close(o, g[f"{key}_{mode}_{i}"], 5e-5)
+    m = nets.FlowNet2(None, batchNorm=True)
+    nets.analytic_weights_(m)
+    m.eval()
+    with torch.no_grad():
+        st = m.stages(nets.analytic_input((1, 2, 256, 256), seed=24))
+    for name, t in zip(("flownetc_flow2", "flownets1_flow2", "flownets2_flow2", "flownetsd_flow2"), st[:4]):
+        _close(t, g[f"flownet2_{name}"], 5e-5)
+    _close(st[-1][:, :, ::2, ::2], g["flownet2_fused"], 5e-4)
