@@ -449,6 +449,28 @@ def main():
                 log(f"{nm} batch {bsz}: {others[nm]['pairs_per_s']} pairs/s ({others[nm]['ms_per_step']} ms/step)")
             except Exception as e:                                   # noqa: BLE001
                 others[nm] = {"error": repr(e)}
+        # the FlowNet2 stack (inference forward only so far), registration-wrapper shaped
+        try:
+            import mireg
+            from mireg.synth import make_pairs
+            reg2 = mireg.opticalFlowReg("flownet2", precision=args.precision).to(dev).eval()
+            x2 = make_pairs(8, 256, seed=6)[0].to(dev)
+            with torch.no_grad():
+                for _ in range(2):
+                    reg2(x2)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    reg2(x2)
+                torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / 5
+            others["flownet2_eval"] = {"pairs_per_s": round(8 / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 3), "batch": 8,
+                                       "note": "opticalFlowReg('flownet2') forward + 2 warps, eval mode, eager, 162.5 M parameters"}
+            log(f"flownet2 eval batch 8: {8 / dt2:.1f} pairs/s")
+            del reg2
+            torch.cuda.empty_cache()
+        except Exception as e:                                       # noqa: BLE001
+            others["flownet2_eval"] = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
