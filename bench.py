@@ -449,7 +449,7 @@ def main():
                 log(f"{nm} batch {bsz}: {others[nm]['pairs_per_s']} pairs/s ({others[nm]['ms_per_step']} ms/step)")
             except Exception as e:                                   # noqa: BLE001
                 others[nm] = {"error": repr(e)}
-        # the FlowNet2 stack (inference forward only so far), registration-wrapper shaped
+        # the FlowNet2 stack, registration-wrapper shaped inference
         try:
             import mireg
             from mireg.synth import make_pairs

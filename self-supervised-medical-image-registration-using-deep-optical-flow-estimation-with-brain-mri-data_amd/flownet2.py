@@ -6,21 +6,22 @@ contraction kernels of the hot path (ring / halo GEMMs, thin heads, tiny upsampl
 volume inside FlowNetC); the glue between them is `Resample2d` / `ChannelNorm` / `Upsample` from flownet2_ops.hip plus a
 handful of torch elementwise ops on 1-9 channel images (a subtraction, a scale, the concats).
 
-State of this row: **inference forward only**.  FlowNetC and the two FlowNetS blocks have HIP backward passes of their
-own, FlowNetSD / FlowNetFusion do not yet, so a forward with autograd enabled on trainable parameters raises instead of
-returning flows that cannot be trained through.
+Training: every sub-network is ONE autograd function whose backward is a HIP backward pass (FlowNetC's own; the FlowNetS
+blocks and FlowNetFusion also return the gradient of their input, which the chain needs because their inputs are built
+from the upstream flows), so `loss.backward()` through `FlowNet2` / `opticalFlowReg("flownet2")` works like the
+reference's.  Eager launches; the fused `RegistrationTrainer` step does not cover this predictor.
 """
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 import torch.nn as nn
 
-from .engine import F32, BatchNormAct, nchw_to_view
+from .engine import F32, BatchNormAct, lrelu_bwd, nchw_to_view, zero_tensors
 from .flownet2_ops import ChannelNorm, Resample2d, Upsample
 from .flownetc import FlowNetC
-from .flownets import DECONV, ENCODER, PREDICT, SLOPE, FlowNetSEngine, PredictorEngineBase, conv_block
+from .flownets import DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, FlowNetSEngine, PredictorEngineBase, conv_block
 
 # (name, cin, cout, stride), all 3x3 -- flownet2/networks/FlowNetSD.py:17-29
 SD_ENCODER = [("conv0", 2, 64, 1), ("conv1", 64, 64, 2), ("conv1_1", 64, 128, 1), ("conv2", 128, 128, 2), ("conv2_1", 128, 128, 1),
@@ -52,14 +53,9 @@ def _xavier_(mod: nn.Module) -> None:
             nn.init.xavier_uniform_(m.weight)
 
 
-def _inference_only(mod: nn.Module, what: str) -> None:
-    if torch.is_grad_enabled() and any(p.requires_grad for p in mod.parameters()):
-        raise NotImplementedError(f"mireg.{what}: only the inference forward is built (no HIP backward yet); call it under "
-                                  "torch.no_grad() or freeze its parameters")
-
-
-class _ForwardEngine(PredictorEngineBase):
-    """Forward-only engine helpers: conv (+BatchNorm) + activation blocks over NHWC views."""
+class _StackEngine(PredictorEngineBase, FlowNetDecoderMixin):
+    """Engine helpers shared by FlowNetSD and FlowNetFusion: conv (+BatchNorm) + activation blocks over NHWC views, forward and
+    backward (`chain_backward`, the wgrad side stream and the gradient bookkeeping come from the FlowNetS machinery)."""
 
     def block(self, name: str, src, dst, training: bool, slope: float = SLOPE) -> None:
         lay = self.layers[name]
@@ -76,15 +72,64 @@ class _ForwardEngine(PredictorEngineBase):
             self.bns[name] = BatchNormAct(seq[1], self.ws, slope)
             self.raw[name] = self.ws.new(self.B, *out_hw, conv.out_channels)
 
+    # ---- backward pieces --------------------------------------------------------------------------------------------
+    def load_flow_grad(self, g: Optional[torch.Tensor], dst) -> None:
+        if g is None:
+            zero_tensors([dst.buf])
+        else:
+            nchw_to_view(g.float().contiguous(), 0, 2, dst)
 
-class FlowNetSDEngine(_ForwardEngine):
+    def head_backward(self, name: str, feat, dflow, dfeat) -> None:
+        """predict_flow: bias gradient, backward-data into dfeat (overwrites), backward-weights on the side stream."""
+        pf = self.layers[name]
+        ready = self.mark()
+        pf.run_bias_grad(dflow)
+        pf.run_dgrad_form(dflow, dfeat)
+        self.wgrad_async(pf, feat, dflow, after=ready)
+
+    def inter_backward(self, name: str, src, dinter, dsrc) -> None:
+        """i_conv (conv with bias [+ BatchNorm], no activation): dinter = gradient of its output; dsrc is overwritten."""
+        lay = self.layers[name]
+        if name in self.bns:
+            self.bns[name].backward(self.raw[name], dinter, self.draw[name])
+            dy = self.draw[name]
+        else:
+            dy = dinter
+        ready = self.mark()
+        lay.run_bias_grad(dy)
+        lay.run_dgrad_form(dy, dsrc)
+        self.wgrad_async(lay, src, dy, after=ready)
+
+    def up_backward(self, name: str, gup, flow_coarse, dflow_coarse, accumulate: bool) -> None:
+        """ConvTranspose2d(2, 2, 4, 2, 1) flow upsampler: gup = gradient of its (fine) output slice."""
+        up = self.layers[name]
+        ready = self.mark()
+        up.run_bias_grad(gup)
+        up.run_fwd_form(gup, dflow_coarse, bias=False, accumulate=accumulate)
+        self.wgrad_async(up, gup, flow_coarse, after=ready)
+
+    def deconv_backward(self, name: str, gde, act_slice, src, dsrc) -> None:
+        """deconv + LeakyReLU: gde = gradient of its activated output slice (masked in place); accumulates into dsrc."""
+        de = self.layers[name]
+        lrelu_bwd(gde, act_slice, SLOPE, self.ws)
+        ready = self.mark()
+        de.run_bias_grad(gde)
+        de.run_fwd_form(gde, dsrc, bias=False, accumulate=True)
+        self.wgrad_async(de, gde, src, after=ready)
+
+    def finish_backward(self) -> None:
+        self.join_side()
+        self.unpack_grads()
+
+
+class FlowNetSDEngine(_StackEngine):
     def __init__(self, module: "FlowNetSD", B: int, H: int, W: int, device, dtype: torch.dtype):
         super().__init__(module, B, H, W, device, dtype)
         if H % 64 or W % 64:
             raise RuntimeError(f"FlowNetSD engine needs H, W divisible by 64, got {H}x{W}")
         ws, m, new = self.ws, module, self.ws.new
         hs = {lvl: (H >> lvl, W >> lvl) for lvl in range(0, 7)}
-        self.hs, self.raw = hs, {}
+        self.hs, self.raw, self.bn, self.grads_ready = hs, {}, m.batchNorm, False
         lvl = 0
         for name, cin, cout, s in SD_ENCODER:
             lvl += s - 1
@@ -139,15 +184,64 @@ class FlowNetSDEngine(_ForwardEngine):
             flows += [self.flow32[l].nchw() for l in (3, 4, 5, 6)]
         return flows
 
+    def _ensure_grad_buffers(self) -> None:
+        if self.grads_ready:
+            return
+        new, hs, B = self.ws.new, self.hs, self.B
+        self.dcat = {l: new(B, *hs[l], v.C) for l, v in self.cat.items()}
+        self.dinter = {l: new(B, *hs[l], v.C) for l, v in self.inter.items()}
+        self.dflowT = {l: new(B, *hs[l], 2) for l in SD_PREDICT}
+        self.da61, self.da6 = new(B, *hs[6], 1024), new(B, *hs[6], 1024)
+        self.da5, self.da4, self.da3 = new(B, *hs[5], 512), new(B, *hs[4], 512), new(B, *hs[3], 256)
+        self.da2, self.da11, self.da1, self.da0 = new(B, *hs[2], 128), new(B, *hs[1], 128), new(B, *hs[1], 64), new(B, *hs[0], 64)
+        self.draw = {n: new(B, v.H, v.W, v.C) for n, v in self.raw.items()}
+        self.grads_ready = True
 
-class FlowNetFusionEngine(_ForwardEngine):
+    def backward(self, gflows) -> None:
+        """gflows: gradients wrt (flow2, flow3, flow4, flow5, flow6) [training arity] or (flow2,), (B,2,h,w) fp32 or None."""
+        self._ensure_grad_buffers()
+        g = list(gflows) + [None] * (5 - len(gflows))
+        glvl = {2: g[0], 3: g[1], 4: g[2], 5: g[3], 6: g[4]}
+        c, dc = self.cat, self.dcat
+        # decoder, fine to coarse (FlowNetSD.py:77-100 backwards): dcat[l] is complete when level l is entered
+        self.load_flow_grad(glvl[2], self.dflowT[2])
+        self.head_backward("predict_flow2", self.inter[2], self.dflowT[2], self.dinter[2])
+        self.inter_backward("inter_conv2", c[2], self.dinter[2], dc[2])
+        for lvl in (2, 3, 4, 5):
+            cs, cd, up = self.skip_c[lvl], DECONV[lvl][1], lvl + 1
+            self.load_flow_grad(glvl[up], self.dflowT[up])
+            self.up_backward(f"up{up}", dc[lvl].slice(cs + cd, 2), self.flowT[up], self.dflowT[up], accumulate=True)
+            if up == 6:
+                src, dsrc = self.a61, self.da61
+                self.head_backward("predict_flow6", src, self.dflowT[6], dsrc)
+            else:
+                src, dsrc = c[up], dc[up]
+                self.head_backward(f"predict_flow{up}", self.inter[up], self.dflowT[up], self.dinter[up])
+                self.inter_backward(f"inter_conv{up}", src, self.dinter[up], dsrc)
+            self.deconv_backward(f"deconv{lvl}", dc[lvl].slice(cs, cd), c[lvl].slice(cs, cd), src, dsrc)
+        # encoder, deep to shallow; the concat slices already hold the decoder's contributions
+        s2, s3, s4, s5 = c[2].slice(0, 128), c[3].slice(0, 256), c[4].slice(0, 512), c[5].slice(0, 512)
+        d2, d3, d4, d5 = dc[2].slice(0, 128), dc[3].slice(0, 256), dc[4].slice(0, 512), dc[5].slice(0, 512)
+        for name, src, dst, dsrc, acc, ddst in (
+                ("conv6_1", self.a6, self.a61, self.da6, False, self.da61), ("conv6", s5, self.a6, d5, True, self.da6),
+                ("conv5_1", self.a5, s5, self.da5, False, d5), ("conv5", s4, self.a5, d4, True, self.da5),
+                ("conv4_1", self.a4, s4, self.da4, False, d4), ("conv4", s3, self.a4, d3, True, self.da4),
+                ("conv3_1", self.a3, s3, self.da3, False, d3), ("conv3", s2, self.a3, d2, True, self.da3),
+                ("conv2_1", self.a2, s2, self.da2, False, d2), ("conv2", self.a11, self.a2, self.da11, False, self.da2),
+                ("conv1_1", self.a1, self.a11, self.da1, False, self.da11), ("conv1", self.a0, self.a1, self.da0, False, self.da1),
+                ("conv0", self.x8, self.a0, None, False, self.da0)):
+            self.chain_backward(name, src, dst, dsrc, acc, ddst)
+        self.finish_backward()
+
+
+class FlowNetFusionEngine(_StackEngine):
     def __init__(self, module: "FlowNetFusion", B: int, H: int, W: int, device, dtype: torch.dtype):
         super().__init__(module, B, H, W, device, dtype)
         if H % 4 or W % 4:
             raise RuntimeError(f"FlowNetFusion engine needs H, W divisible by 4, got {H}x{W}")
         m, new = module, self.ws.new
         hs = {lvl: (H >> lvl, W >> lvl) for lvl in range(0, 3)}
-        self.raw = {}
+        self.hs, self.raw, self.bn, self.grads_ready = hs, {}, m.batchNorm, False
         for name, s, lvl in (("conv0", 1, 0), ("conv1", 2, 1), ("conv1_1", 1, 1), ("conv2", 2, 2), ("conv2_1", 1, 2)):
             self.add_block(name, getattr(m, name), s, hs[lvl])
         self.add_conv("deconv1", m.deconv1[0], 2, 1)
@@ -184,6 +278,74 @@ class FlowNetFusionEngine(_ForwardEngine):
         self.block("inter_conv0", self.cat0, self.i0, training, slope=1.0)
         L["predict_flow0"].run_fwd_form(self.i0, self.flowT[0], y32=self.flow32[0])
         return self.flow32[0].nchw()
+
+    def _ensure_grad_buffers(self) -> None:
+        if self.grads_ready:
+            return
+        new, hs, B = self.ws.new, self.hs, self.B
+        self.dcat0, self.dcat1 = new(B, *hs[0], 82), new(B, *hs[1], 162)
+        self.da21, self.da2, self.da1 = new(B, *hs[2], 128), new(B, *hs[2], 128), new(B, *hs[1], 64)
+        self.di1, self.di0 = new(B, *hs[1], 32), new(B, *hs[0], 16)
+        self.dflowT = {l: new(B, *hs[l], 2) for l in (2, 1, 0)}
+        self.dx9 = new(B, *hs[0], 9)
+        self.draw = {n: new(B, v.H, v.W, v.C) for n, v in self.raw.items()}
+        self.grads_ready = True
+
+    def backward(self, gflows) -> None:
+        """gflows: (gradient wrt flow0,) as (B,2,H,W) fp32.  Leaves d loss / d input in dx9 (FlowNetFusion.py:43-66 backwards)."""
+        self._ensure_grad_buffers()
+        c0, c1, d0, d1 = self.cat0, self.cat1, self.dcat0, self.dcat1
+        self.load_flow_grad(gflows[0], self.dflowT[0])
+        self.head_backward("predict_flow0", self.i0, self.dflowT[0], self.di0)
+        self.inter_backward("inter_conv0", c0, self.di0, d0)
+        # level 0 -> 1
+        self.up_backward("up1", d0.slice(80, 2), self.flowT[1], self.dflowT[1], accumulate=False)
+        self.head_backward("predict_flow1", self.i1, self.dflowT[1], self.di1)
+        self.inter_backward("inter_conv1", c1, self.di1, d1)
+        self.deconv_backward("deconv0", d0.slice(64, 16), c0.slice(64, 16), c1, d1)
+        # level 1 -> 2
+        self.up_backward("up2", d1.slice(160, 2), self.flowT[2], self.dflowT[2], accumulate=False)
+        self.head_backward("predict_flow2", self.a21, self.dflowT[2], self.da21)
+        self.deconv_backward("deconv1", d1.slice(128, 32), c1.slice(128, 32), self.a21, self.da21)
+        for name, src, dst, dsrc, acc, ddst in (
+                ("conv2_1", self.a2, self.a21, self.da2, False, self.da21), ("conv2", c1.slice(0, 128), self.a2, d1.slice(0, 128), True, self.da2),
+                ("conv1_1", self.a1, c1.slice(0, 128), self.da1, False, d1.slice(0, 128)),
+                ("conv1", c0.slice(0, 64), self.a1, d0.slice(0, 64), True, self.da1),
+                ("conv0", self.x9, c0.slice(0, 64), self.dx9, False, d0.slice(0, 64))):
+            self.chain_backward(name, src, dst, dsrc, acc, ddst)
+        self.finish_backward()
+
+    def input_grad(self) -> torch.Tensor:
+        return self.dx9.nchw().float()
+
+
+class _StackFn(torch.autograd.Function):
+    """One sub-network of the stack as one autograd node: forward = the engine's kernel sequence, backward = its HIP backward
+    pass.  `skip` leading engine outputs are not returned (the FlowNetS engine's 256x256 top flow)."""
+
+    @staticmethod
+    def forward(ctx, module, cls, channels, skip, want_dx, x, *params):
+        eng = module._engine(x, cls, channels)
+        if want_dx:
+            eng.want_dx = True
+        out = eng.forward(x, module.training)
+        eng.training_cache = module.training
+        outs = list(out) if isinstance(out, (list, tuple)) else [out]
+        ctx.eng, ctx.module, ctx.skip, ctx.dx = eng, module, skip, want_dx and x.requires_grad
+        ctx.n_out = len(outs)
+        return tuple(outs[skip:])
+
+    @staticmethod
+    def backward(ctx, *g):
+        eng = ctx.eng
+        g = (None,) * ctx.skip + tuple(g)
+        if isinstance(eng, FlowNetSEngine):
+            g = g + (None,) * (6 - len(g))
+        eng.autograd_backward(g)
+        table = eng.param_grads()
+        grads = tuple(table[id(p)].clone() if id(p) in table else None for p in ctx.module.parameters())
+        dx = eng.input_grad() if ctx.dx else None
+        return (None, None, None, None, None, dx) + grads
 
 
 class _EngineCache:
@@ -227,9 +389,8 @@ class FlowNet2S(nn.Module, _EngineCache):
         self._engines: Dict[tuple, FlowNetSEngine] = {}
 
     def forward(self, x):
-        _inference_only(self, "FlowNet2S")
-        flows = self._engine(x, FlowNetSEngine, self.input_channels).forward(x.float(), self.training)
-        return tuple(flows[1:])                               # the engine's first output is the 256x256 top flow of FlowNetS/FlowNetS.py:83
+        # the engine's first output is the 256x256 top flow of FlowNetS/FlowNetS.py:83, which this variant does not have
+        return _StackFn.apply(self, FlowNetSEngine, self.input_channels, 1, True, x.float(), *self.parameters())
 
 
 class FlowNetSD(nn.Module, _EngineCache):
@@ -253,8 +414,7 @@ class FlowNetSD(nn.Module, _EngineCache):
         self._engines: Dict[tuple, FlowNetSDEngine] = {}
 
     def forward(self, x):
-        _inference_only(self, "FlowNetSD")
-        return tuple(self._engine(x, FlowNetSDEngine, 2).forward(x.float(), self.training))
+        return _StackFn.apply(self, FlowNetSDEngine, 2, 0, False, x.float(), *self.parameters())
 
 
 class FlowNetFusion(nn.Module, _EngineCache):
@@ -281,8 +441,7 @@ class FlowNetFusion(nn.Module, _EngineCache):
         self._engines: Dict[tuple, FlowNetFusionEngine] = {}
 
     def forward(self, x):
-        _inference_only(self, "FlowNetFusion")
-        return self._engine(x, FlowNetFusionEngine, 9).forward(x.float(), self.training)
+        return _StackFn.apply(self, FlowNetFusionEngine, 9, 0, True, x.float(), *self.parameters())[0]
 
 
 class FlowNet2(nn.Module):
@@ -311,7 +470,6 @@ class FlowNet2(nn.Module):
 
     def stages(self, inputs: torch.Tensor):
         """(flownetc_flow2, flownets1_flow2, flownets2_flow2, flownetsd_flow2, fused flow) -- flownet2/models.py:128-189."""
-        _inference_only(self, "FlowNet2")
         inputs = inputs.float()
         x1, x2 = inputs[:, 0:1].contiguous(), inputs[:, 1:2].contiguous()
         c2 = self.flownetc(inputs)[0].contiguous()            # engine outputs are permuted views of buffers the next forward reuses

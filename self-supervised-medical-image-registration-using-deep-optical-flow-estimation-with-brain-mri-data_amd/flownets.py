@@ -428,8 +428,9 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
         self.da5, self.da6 = new(B, *hs[5], 512), new(B, *hs[6], 1024)
         self.draw = {n: new(B, v.H, v.W, v.C) for n, v in self.raw.items()}
         dc = self.dcat
+        self.dx8 = new(B, self.H, self.W, self.cin) if getattr(self, "want_dx", False) else None
         self.enc_dio = {  # (grad wrt conv input, accumulate?), grad wrt conv output (activated)
-            "conv1": (None, False, self.da1), "conv2": (self.da1, False, dc[2].slice(0, 128)),
+            "conv1": (self.dx8, False, self.da1), "conv2": (self.da1, False, dc[2].slice(0, 128)),
             "conv3": (dc[2].slice(0, 128), True, self.da3), "conv3_1": (self.da3, False, dc[3].slice(0, 256)),
             "conv4": (dc[3].slice(0, 256), True, self.da4), "conv4_1": (self.da4, False, dc[4].slice(0, 512)),
             "conv5": (dc[4].slice(0, 512), True, self.da5), "conv5_1": (self.da5, False, dc[5].slice(0, 512)),
@@ -473,6 +474,12 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
         bn = lambda names: names if self.bn else ()
         return [self.flat_range(self.DEC_LAYERS), self.flat_range(self.PHASE_ENC[0], bn(self.PHASE_ENC[0])),
                 self.flat_range(self.PHASE_ENC[1], bn(self.PHASE_ENC[1]))]
+
+    def input_grad(self) -> torch.Tensor:
+        """d loss / d x as (B, cin, H, W) fp32 (only with `want_dx`, set before the first backward)."""
+        if self.dx8 is None:
+            raise RuntimeError("FlowNetSEngine: the input gradient was not requested before the gradient buffers were built")
+        return self.dx8.nchw().float()
 
     def backward(self, gflows: Sequence[Optional[torch.Tensor]]) -> None:
         """gflows: gradients wrt (flow0, flow2, flow3, flow4, flow5, flow6) as (B,2,h,w) fp32 or None."""

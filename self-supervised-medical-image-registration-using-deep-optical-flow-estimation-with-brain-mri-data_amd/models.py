@@ -40,7 +40,7 @@ class opticalFlowReg(nn.Module):
         if "raft" in name:
             raise NotImplementedError(
                 f"predictor '{conv_predictor}' is outside the accelerated hot path (SURVEY section 8f); "
-                "available: 'flownets' (default), 'flownetc', 'pwc', 'flownet2' (inference)")
+                "available: 'flownets' (default), 'flownetc', 'pwc', 'flownet2'")
         if "flownet2" in name:                              # reference models.py:212-225: FlowNet2(args, batchNorm=True)
             from .flownet2 import FlowNet2
             self.predictor = FlowNet2(None, batchNorm=True, precision=precision)

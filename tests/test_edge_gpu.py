@@ -32,10 +32,10 @@ def test_predictors_reject_unsupported_image_sizes_loudly():
     m = mireg.opticalFlowReg("flownets", precision="fp32").to(DEV)
     with pytest.raises(RuntimeError, match="divisible by 64"):
         m(torch.zeros(1, 2, 96, 100, device=DEV))
-    # reference models.py:208-252: any other string selects FlowNetS; the two predictors outside the hot path say so
+    # reference models.py:208-252: any other string selects FlowNetS; the predictor outside the hot path (RAFT) says so
     assert type(mireg.opticalFlowReg("anything-else").predictor).__name__ == "FlowNetS"
     with pytest.raises(NotImplementedError):
-        mireg.opticalFlowReg("flownet2")
+        mireg.opticalFlowReg("raft")
 
 
 @pytest.mark.parametrize("B", [1, 3])

@@ -45,8 +45,6 @@ def test_flownet2_subnetworks_fp32_golden(golden, which):
         tol = 3e-3 if mode == "train" else 5e-4
         for i, o in enumerate(out):
             assert _err(o, g[f"{key}_{mode}_{i}"]) <= tol, (mode, i, _err(o, g[f"{key}_{mode}_{i}"]))
-    with pytest.raises(NotImplementedError):               # no silent untrainable flows: autograd on trainable parameters raises
-        m(x)
 
 
 def test_flownet2_chain_fp32_golden_and_bf16(golden):
@@ -82,3 +80,81 @@ def test_registration_wrapper_with_flownet2():
         flows, warped, _, _ = reg(x)
     assert len(flows) == 2 and len(warped) == 2 and flows[0].shape == (2, 2, 256, 256) and warped[0].shape == (2, 1, 256, 256)
     assert torch.isfinite(flows[0]).all() and torch.isfinite(warped[0]).all()
+    # the reference's training loop on it (train.py:48-57): forward, OFEloss, backward, Adam(eps=1e-4)
+    reg.train()
+    opt = mireg.Adam(reg.parameters(), 1e-4, eps=1e-4)
+    before = [p.detach().clone() for p in reg.parameters()]
+    flows, warped, _, _ = reg(x)
+    loss = mireg.OFEloss(flows, warped, x[:, 0:1])[3]
+    opt.zero_grad()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in reg.parameters())
+    opt.step()
+    moved = sum(int(not torch.equal(a, b)) for a, b in zip(before, reg.parameters()))
+    assert moved > 0.9 * len(before) and torch.isfinite(loss)
+
+
+def _grad_report(m_hip, m_cpu):
+    """(relative L2 over all parameter gradients together, worst per-parameter relative L2 among the gradients that carry
+    at least 1e-3 of the total norm)."""
+    gh = {k: p.grad.detach().double().cpu().flatten() for k, p in m_hip.named_parameters()}
+    gc = {k: p.grad.detach().double().flatten() for k, p in m_cpu.named_parameters()}
+    assert set(gh) == set(gc)
+    tot = torch.cat([gc[k] for k in gc]).norm().item()
+    err = torch.cat([gh[k] - gc[k] for k in gc]).norm().item()
+    worst = max(((gh[k] - gc[k]).norm() / gc[k].norm()).item() for k in gc if gc[k].norm().item() > 1e-3 * tot)
+    return err / tot, worst
+
+
+@pytest.mark.parametrize("which", ["FlowNetSD", "FlowNetFusion", "FlowNet2S"])
+def test_flownet2_subnetworks_backward_vs_cpu_autograd(which):
+    """HIP backward of the stack's sub-networks (every parameter gradient, and the input gradient where the chain needs one)
+    against torch autograd through the CPU restatement, fp32, train-mode BatchNorm.  Bounds as for FlowNetS (G1): LeakyReLU
+    kink flips and few-sample BatchNorms move any fp32 implementation by a few 1e-3 of a gradient's norm."""
+    import mireg
+    shape, seed, ocls = {"FlowNetSD": ((2, 2, 128, 128), 31, nets.FlowNetSD), "FlowNetFusion": ((2, 9, 64, 64), 32, nets.FlowNetFusion),
+                         "FlowNet2S": ((2, 6, 128, 128), 33, nets.FlowNet2S)}[which]
+    o = ocls(None, batchNorm=True)
+    nets.analytic_weights_(o)
+    m = getattr(mireg, which)(None, batchNorm=True, precision="fp32")
+    m.load_state_dict(o.state_dict())
+    m = m.to(DEV)
+    o.train(); m.train()
+    x = nets.analytic_input(shape, seed=seed, lo=-1.0, hi=1.0)
+    need_dx = which != "FlowNetSD"
+    xc = x.clone().requires_grad_(need_dx)
+    xg = x.clone().to(DEV).requires_grad_(need_dx)
+    oc, og = o(xc), m(xg)
+    oc, og = (oc if isinstance(oc, tuple) else (oc,)), (og if isinstance(og, tuple) else (og,))
+    gen = torch.Generator().manual_seed(seed)
+    cots = [torch.randn(t.shape, generator=gen) for t in oc]
+    sum((a * c).sum() for a, c in zip(oc, cots)).backward()
+    sum((a * c.to(DEV)).sum() for a, c in zip(og, cots)).backward()
+    total, worst = _grad_report(m, o)
+    assert total < 1e-2 and worst < 3e-2, (total, worst)
+    if need_dx:
+        rel = ((xg.grad.cpu() - xc.grad).norm() / xc.grad.norm()).item()
+        assert rel < 1e-2, rel
+
+
+def test_flownet2_trains_end_to_end():
+    """loss.backward() through the whole chain (five sub-networks, three warps): gradients reach every sub-network and agree
+    in direction with torch autograd through the CPU restatement (cosine per sub-network; the chain multiplies flow errors by
+    div_flow at every stage, so element-wise bounds are not meaningful here)."""
+    import mireg
+    o = nets.FlowNet2(None, batchNorm=True)
+    nets.analytic_weights_(o)
+    m = mireg.FlowNet2(None, batchNorm=True, precision="fp32")
+    m.load_state_dict(o.state_dict())
+    m = m.to(DEV)
+    o.train(); m.train()
+    x = nets.analytic_input((2, 2, 256, 256), seed=41)
+    cot = torch.randn(2, 2, 256, 256, generator=torch.Generator().manual_seed(42))
+    (o(x)[0] * cot).sum().backward()
+    (m(x.to(DEV))[0] * cot.to(DEV)).sum().backward()
+    for sub in ("flownetc", "flownets_1", "flownets_2", "flownets_d", "flownetfusion"):
+        gh = torch.cat([p.grad.detach().double().cpu().flatten() for p in getattr(m, sub).parameters()])
+        gc = torch.cat([p.grad.detach().double().flatten() for p in getattr(o, sub).parameters()])
+        assert gc.norm().item() > 0
+        cos = torch.nn.functional.cosine_similarity(gh, gc, dim=0).item()
+        assert cos > 0.99, (sub, cos)
