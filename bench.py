@@ -467,6 +467,29 @@ def main():
             others["flownet2_eval"] = {"pairs_per_s": round(8 / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 3), "batch": 8,
                                        "note": "opticalFlowReg('flownet2') forward + 2 warps, eval mode, eager, 162.5 M parameters"}
             log(f"flownet2 eval batch 8: {8 / dt2:.1f} pairs/s")
+            # its training step as the reference runs it (train.py:48-57): forward, OFEloss, autograd backward (HIP per sub-network), Adam
+            reg2.train()
+            opt2 = mireg.Adam(reg2.parameters(), 1e-4, eps=1e-4)
+
+            def f2_train():
+                flows, warped, _, _ = reg2(x2)
+                loss = mireg.OFEloss(flows, warped, x2[:, 0:1])[3]
+                opt2.zero_grad()
+                loss.backward()
+                opt2.step()
+                return loss
+            for _ in range(2):
+                f2_train()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                l2 = f2_train()
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / 4
+            others["flownet2_train"] = {"pairs_per_s": round(8 / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3), "batch": 8, "loss_total": float(l2.detach()),
+                                        "note": "forward + OFEloss + HIP backward of the five sub-networks through torch.autograd + mireg.Adam, eager"}
+            log(f"flownet2 train batch 8: {8 / dt2:.1f} pairs/s")
+            del opt2
             del reg2
             torch.cuda.empty_cache()
         except Exception as e:                                       # noqa: BLE001

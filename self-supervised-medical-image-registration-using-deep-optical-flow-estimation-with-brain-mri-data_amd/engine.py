@@ -756,6 +756,7 @@ class BatchNormAct:
 
     def __init__(self, bn: torch.nn.BatchNorm2d, ws: Workspace, slope: float = 0.1):
         self.bn, self.ws, self.slope = bn, ws, slope
+        self.pending = 0                 # training forwards not yet added to bn.num_batches_tracked (flushed when a state_dict is taken)
         C = bn.num_features
         self.C = C
         self.partial = torch.zeros(self.MAX_BLOCKS * 2 * C, device=ws.device, dtype=F32)

@@ -21,7 +21,8 @@ import torch.nn as nn
 from .engine import F32, BatchNormAct, lrelu_bwd, nchw_to_view, zero_tensors
 from .flownet2_ops import ChannelNorm, Resample2d, Upsample
 from .flownetc import FlowNetC
-from .flownets import DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, FlowNetSEngine, PredictorEngineBase, conv_block
+from .flownets import (DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, FlowNetSEngine, PredictorEngineBase, conv_block,
+                       count_bn_batches, install_bn_counter_hook)
 
 # (name, cin, cout, stride), all 3x3 -- flownet2/networks/FlowNetSD.py:17-29
 SD_ENCODER = [("conv0", 2, 64, 1), ("conv1", 64, 64, 2), ("conv1_1", 64, 128, 1), ("conv2", 128, 128, 2), ("conv2_1", 128, 128, 1),
@@ -330,6 +331,8 @@ class _StackFn(torch.autograd.Function):
             eng.want_dx = True
         out = eng.forward(x, module.training)
         eng.training_cache = module.training
+        if module.training:
+            count_bn_batches(eng)
         outs = list(out) if isinstance(out, (list, tuple)) else [out]
         ctx.eng, ctx.module, ctx.skip, ctx.dx = eng, module, skip, want_dx and x.requires_grad
         ctx.n_out = len(outs)
@@ -365,6 +368,7 @@ class _EngineCache:
             if C != channels:
                 raise RuntimeError(f"{type(self).__name__} expects (B,{channels},H,W), got {tuple(x.shape)}")
             self._engines[key] = cls(self, B, H, W, x.device, dtype)
+            install_bn_counter_hook(self)
         return self._engines[key]
 
 

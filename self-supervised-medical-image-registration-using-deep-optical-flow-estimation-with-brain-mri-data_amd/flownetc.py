@@ -18,7 +18,8 @@ import torch.nn as nn
 from . import _lib
 from .correlation import correlation_bwd_views, Correlation, correlation_views
 from .engine import BatchNormAct, F32, _stream, lrelu_bwd, nchw_to_view
-from .flownets import DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block
+from .flownets import (DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block, count_bn_batches,
+                       install_bn_counter_hook)
 
 
 class FlowNetCEngine(PredictorEngineBase, FlowNetDecoderMixin):
@@ -184,7 +185,10 @@ class _FlowNetCFn(torch.autograd.Function):
     def forward(ctx, module, x, *params):
         eng = module.engine_for(x)
         ctx.eng, ctx.module = eng, module
-        return tuple(eng.forward(x, module.training))
+        out = tuple(eng.forward(x, module.training))
+        if module.training:
+            count_bn_batches(eng)
+        return out
 
     @staticmethod
     def backward(ctx, *g):
@@ -236,9 +240,14 @@ class FlowNetC(nn.Module):
             if C != 2:
                 raise RuntimeError(f"FlowNetC expects (B,2,H,W) [fixed, moving], got {tuple(x.shape)}")
             self._engines[key] = FlowNetCEngine(self, B, H, W, x.device, dtype)
+            install_bn_counter_hook(self)
         return self._engines[key]
 
     def forward(self, x):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return tuple(_FlowNetCFn.apply(self, x.float(), *self.parameters()))
-        return tuple(self.engine_for(x).forward(x.float(), self.training))
+        eng = self.engine_for(x)
+        out = tuple(eng.forward(x.float(), self.training))
+        if self.training:
+            count_bn_batches(eng)
+        return out

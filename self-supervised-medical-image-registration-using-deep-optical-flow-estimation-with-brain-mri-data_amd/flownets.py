@@ -32,6 +32,28 @@ def conv_block(bn: bool, cin: int, cout: int, k: int = 3, stride: int = 1) -> nn
     return nn.Sequential(*layers)
 
 
+def count_bn_batches(eng) -> None:
+    """One training forward has run through every BatchNorm of the engine (torch increments num_batches_tracked per module
+    call; siamese streams wrap one module twice and so count twice, as in the reference)."""
+    for b in eng.bns.values():
+        b.pending += 1
+
+
+def install_bn_counter_hook(module: nn.Module) -> None:
+    """Keep BatchNorm2d.num_batches_tracked as torch would (train.py:183-201 writes it into every checkpoint) without a launch
+    per layer per step: forwards are counted on the host and added when a state_dict is taken."""
+    if getattr(module, "_bn_counter_hook", None) is not None:
+        return
+
+    def flush(mod, prefix, keep_vars):
+        for eng in getattr(mod, "_engines", {}).values():
+            for b in eng.bns.values():
+                if b.pending:
+                    b.bn.num_batches_tracked += b.pending
+                    b.pending = 0
+    module._bn_counter_hook = module.register_state_dict_pre_hook(flush)
+
+
 class PredictorEngineBase:
     """Shared by the predictors: weight packing, gradient unpacking, parameter <-> grad bookkeeping."""
 
@@ -492,6 +514,8 @@ class _FlowNetSFn(torch.autograd.Function):
     def forward(ctx, module, x, *params):
         eng = module.engine_for(x)
         flows = eng.forward(x, module.training)
+        if module.training:
+            count_bn_batches(eng)
         ctx.eng, ctx.module = eng, module
         return tuple(flows)
 
@@ -552,6 +576,7 @@ class FlowNetS(nn.Module):
             if C != 2:
                 raise RuntimeError(f"FlowNetS expects (B,2,H,W) [fixed, moving], got {tuple(x.shape)}")
             self._engines[key] = FlowNetSEngine(self, B, H, W, x.device, dtype)
+            install_bn_counter_hook(self)
         return self._engines[key]
 
     def forward(self, x):

@@ -53,10 +53,27 @@ class opticalFlowReg(nn.Module):
         else:
             self.predictor = FlowNetS(batchNorm=True, precision=precision)
         if pretrained is not None:  # never a hard-coded path
-            sd = torch.load(pretrained, map_location="cpu")
-            sd = sd.get("state_dict", sd.get("model_state_dict", sd))
-            self.load_state_dict(sd, strict=False)
+            self.load_pretrained(pretrained)
         self._grid = None
+
+    def load_pretrained(self, path: str) -> None:
+        """Weights from a checkpoint file: a registration checkpoint of the reference (`predictor.`-prefixed keys, train.py:183-201)
+        or a bare predictor checkpoint as the optical-flow repositories publish them (un-prefixed keys, RGB first layers folded to
+        one channel per image as reference models.py:247,305-309 does).  Raises when nothing in the file matches the model."""
+        from .checkpoint import fold_rgb_pretrained
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd.get("model_state_dict", sd))
+        target = self if any(k.startswith("predictor.") for k in sd) else self.predictor
+        own = target.state_dict()
+        sd = dict(sd)
+        for k, v in list(sd.items()):                        # first layers trained on RGB: 3 (one image) or 6 (two images) input channels
+            if k in own and v.dim() == 4 and v.shape != own[k].shape and v.shape[1] == 3 * own[k].shape[1] and v.shape[0] == own[k].shape[0]:
+                sd = fold_rgb_pretrained(sd, k, images=own[k].shape[1])
+        matched = [k for k in sd if k in own and sd[k].shape == own[k].shape]
+        if not matched:
+            raise RuntimeError(f"{path}: no tensor of the checkpoint matches this model's parameters "
+                               f"(checkpoint keys like {list(sd)[:3]}, model keys like {list(own)[:3]})")
+        target.load_state_dict({k: sd[k] for k in matched}, strict=False)
 
     def stn(self, flow: torch.Tensor, frame: torch.Tensor) -> torch.Tensor:
         return ops.stn(flow, frame)

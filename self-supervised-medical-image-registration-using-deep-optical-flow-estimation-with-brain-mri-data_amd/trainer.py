@@ -455,6 +455,8 @@ class RegistrationTrainer:
             self._run([f for f, _ in segs])
             self._optim()
             self._warm += 1
+        for b in self.eng.bns.values():                     # BatchNorm2d.num_batches_tracked, added when a state_dict is taken
+            b.pending += 1
         return self.loss.out4
 
     def _capture(self) -> None:

@@ -67,3 +67,29 @@ def test_flo_files(tmp_path):
     open(p, "wb").write(b"nope" + raw[4:])
     with pytest.raises(ValueError):
         ck.read_flo(p)
+
+
+def test_pretrained_loader_accepts_bare_and_prefixed_checkpoints(tmp_path):
+    """opticalFlowReg(pretrained=...) (reference models.py:244-252,305-309): bare predictor checkpoints (un-prefixed keys, RGB
+    first layer) and registration checkpoints (`predictor.` keys) both load; a file that matches nothing raises instead of
+    silently loading zero tensors."""
+    import mireg
+    torch.manual_seed(0)
+    donor = mireg.FlowNetS(batchNorm=True)
+    sd = {k: v.clone() for k, v in donor.state_dict().items()}
+    rgb = torch.randn(64, 6, 7, 7)
+    sd["conv1.0.weight"] = rgb                                                  # FlyingChairs layout: two RGB frames
+    bare = str(tmp_path / "bare.pth.tar")
+    torch.save({"state_dict": sd}, bare)
+    reg = mireg.opticalFlowReg("flownets", pretrained=bare)
+    want = torch.cat([rgb[:, :3].sum(1, keepdim=True), rgb[:, 3:].sum(1, keepdim=True)], 1)
+    assert torch.equal(reg.predictor.conv1[0].weight.detach(), want)
+    assert torch.equal(reg.predictor.conv6_1[0].weight.detach(), sd["conv6_1.0.weight"])
+    full = str(tmp_path / "full.pt")
+    torch.save({"model_state_dict": reg.state_dict()}, full)
+    reg2 = mireg.opticalFlowReg("flownets", pretrained=full)
+    assert all(torch.equal(a, b) for a, b in zip(reg.state_dict().values(), reg2.state_dict().values()))
+    junk = str(tmp_path / "junk.pt")
+    torch.save({"something.else": torch.zeros(3)}, junk)
+    with pytest.raises(RuntimeError, match="no tensor of the checkpoint matches"):
+        mireg.opticalFlowReg("flownets", pretrained=junk)

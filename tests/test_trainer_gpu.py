@@ -237,21 +237,33 @@ def test_dp2_sync_loss_stats_is_the_single_process_step_on_the_concatenated_batc
     from mireg.synth import make_pairs
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     tmp = tempfile.mkdtemp(prefix="mireg_dp_")
-    mp.spawn(_dp_sync_worker, args=(2, port, tmp), nprocs=2, join=True)
-    r0, r1 = (torch.load(os.path.join(tmp, f"rank{r}.pt")) for r in range(2))
-    assert torch.equal(r0[0], r1[0]) and r0[1] == r1[1]
-    model = mireg.opticalFlowReg("flownets", precision="fp32")
-    model.predictor = FlowNetS(batchNorm=False, precision="fp32")
-    nets.analytic_weights_(model)
-    model = model.to(DEV)
-    p0 = torch.cat([q.detach().reshape(-1).cpu() for q in model.parameters()])
-    x, _ = make_pairs(4, 64, seed=3)
-    tr = mireg.RegistrationTrainer(model, use_graph=False, autotune=False)
-    losses1 = tr.step(x.to(DEV)).tolist()
-    losses = tr.step(x.to(DEV)).tolist()
-    # same weights, other launch shapes at B=2 vs B=4 (the heads change kernel at 1024 pixels), f64 moments over another partition
+    # same kernels for B=2 per rank and B=4 in one process: the heads switch to the 1x1-GEMM form at 1024 pixels, which would
+    # put another summation order (and, after one Adam step, +-lr differences) between the two runs
+    from mireg import engine
+    old_rows, old_env = engine.THIN_GEMM_ROWS, os.environ.get("MIREG_THIN_GEMM_ROWS")
+    engine.THIN_GEMM_ROWS, os.environ["MIREG_THIN_GEMM_ROWS"] = 10 ** 9, str(10 ** 9)
+    try:
+        mp.spawn(_dp_sync_worker, args=(2, port, tmp), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(tmp, f"rank{r}.pt")) for r in range(2))
+        assert torch.equal(r0[0], r1[0]) and r0[1] == r1[1]
+        model = mireg.opticalFlowReg("flownets", precision="fp32")
+        model.predictor = FlowNetS(batchNorm=False, precision="fp32")
+        nets.analytic_weights_(model)
+        model = model.to(DEV)
+        p0 = torch.cat([q.detach().reshape(-1).cpu() for q in model.parameters()])
+        x, _ = make_pairs(4, 64, seed=3)
+        tr = mireg.RegistrationTrainer(model, use_graph=False, autotune=False)
+        losses1 = tr.step(x.to(DEV)).tolist()
+        losses = tr.step(x.to(DEV)).tolist()
+    finally:
+        engine.THIN_GEMM_ROWS = old_rows
+        if old_env is None:
+            os.environ.pop("MIREG_THIN_GEMM_ROWS", None)
+        else:
+            os.environ["MIREG_THIN_GEMM_ROWS"] = old_env
+    # same weights, other launch shapes at B=2 vs B=4, f64 moments over another partition
     assert all(abs(a - b) <= 1e-6 * abs(b) + 1e-12 for a, b in zip(r0[3], losses1)), (r0[3], losses1)
-    # after one Adam step the weights differ by +-lr wherever a gradient was at rounding level (see below): < 1e-4 of each term
+    # after one Adam step the weights differ by +-lr wherever a gradient was at rounding level (see below)
     assert all(abs(a - b) <= 1e-4 * abs(b) + 1e-12 for a, b in zip(r0[1], losses)), (r0[1], losses)
     # parameters after two steps: Adam turns noise-level gradients (|g| ~ fp32 rounding of a two-half sum) into +-lr moves, so
     # compare the update direction, as the other trainer tests do
@@ -368,3 +380,24 @@ def test_dp2_over_rccl_on_two_gpus():
         tr._optim()
         tr.grad_scale = 1.0
     assert (tr.flat_p.cpu() - ret[0]).abs().max().item() < 5e-6
+
+
+def test_batchnorm_num_batches_tracked_follows_torch():
+    """BatchNorm2d.num_batches_tracked in a state_dict (train.py:183-201 checkpoints it): one per training forward per module
+    call, through the fused trainer (eager warm-up, capture, hipGraph replays) and through the autograd path."""
+    import mireg
+    from mireg.synth import make_pairs
+    torch.manual_seed(0)
+    m = mireg.opticalFlowReg("flownets", precision="bf16").to(DEV)
+    x = make_pairs(2, 64, seed=1)[0].to(DEV)
+    tr = mireg.RegistrationTrainer(m, use_graph=True, autotune=False)
+    for _ in range(5):
+        tr.step(x)
+    sd = m.state_dict()
+    assert all(int(v) == 5 for k, v in sd.items() if k.endswith("num_batches_tracked")), {k: int(v) for k, v in sd.items() if k.endswith("num_batches_tracked")}
+    m.train()
+    flows, warped, _, _ = m(x)
+    with torch.no_grad():
+        m.eval()
+        m(x)
+    assert all(int(v) == 6 for k, v in m.state_dict().items() if k.endswith("num_batches_tracked"))
