@@ -128,7 +128,14 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
   }
   if (bid >= my_tiles) return;                                      // classes with fewer tiles than the grid
-  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  // An XCD's run of tiles shares whichever operand the tile order keeps fixed.  Many pixels (M >= N): m-major, the run shares its
+  // pixels' gathers and re-reads the (small) weights.  Few pixels, many channels (the 4x4 / 8x8 levels: M = 384..1536 against
+  // up to 19 MB of weights): n-major, so that all row tiles of a weight slice sit on ONE XCD and the slice leaves HBM once
+  // instead of once per row tile (conv6_1 forward: 60 MB at the memory side for 26 MB of operands before this).
+  const int tiles_m = (M + BM - 1) / BM;
+  int tile_m, tile_n;
+  if (M < p.N) { tile_n = bid / tiles_m; tile_m = bid - tile_n * tiles_m; }
+  else { tile_m = bid / tiles_n; tile_n = bid - tile_m * tiles_n; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int K = tapsZ * p.taps_y * p.taps_x * p.x_C;
   const int nk_total = (K + BK - 1) / BK;

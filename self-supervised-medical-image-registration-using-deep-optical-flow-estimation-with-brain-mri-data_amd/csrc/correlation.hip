@@ -12,6 +12,8 @@
 #include "mireg_common.h"
 #include "../../include/mireg.h"
 
+#include <cstdlib>
+
 using namespace mireg;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -54,7 +56,9 @@ correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__
   const int r = lane & 31, h = lane >> 5;
   const int D = 2 * R + 1, DD = D * D;
   float (*tile)[33] = reinterpret_cast<float (*)[33]>(dyn + wid * 32 * 33 * 4);     // per-wave 32x32 staging
-  T* otile = reinterpret_cast<T*>(dyn + 4 * 32 * 33 * 4);                            // [32][DD]
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int DDp = (DD + VEC - 1) / VEC * VEC;                                       // row stride: 16-byte aligned rows
+  T* otile = reinterpret_cast<T*>(dyn + 4 * 32 * 33 * 4);                            // [32][DDp]
   const int xt = (W + 31) / 32;
   const float inv_c = 1.f / (float)c_norm;
   const int u = blockIdx.x;
@@ -64,15 +68,19 @@ correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__
   const int xa = x0 + r;                                     // this lane's f1 pixel (A row)
   const T* a_row = f1 + (((long)b * H + y) * W + min(xa, W - 1)) * ld1;
   const bool a_ok = xa < W;
-  for (int e = threadIdx.x; e < 32 * DD; e += 256) otile[e] = (T)0.f;   // out-of-image displacements stay zero
+  for (int e = threadIdx.x; e < 32 * DDp / VEC; e += 256)                 // out-of-image displacements stay zero
+    reinterpret_cast<uint4*>(otile)[e] = make_uint4(0, 0, 0, 0);
   uint4 a_frag[16];                                          // f1 fragments of channels 0..255 (bf16 path)
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int kk = 16 * i + 8 * h;
-      const bool ok = a_ok && kk < C;
-      const uint4 v = *GPTR(const uint4, a_row + (ok ? kk : 0));
-      a_frag[i] = ok ? v : make_uint4(0, 0, 0, 0);
+      a_frag[i] = make_uint4(0, 0, 0, 0);
+      if (16 * i < C) {                                        // block-uniform: PWC's 32..196-channel levels use 2..13 of the 16
+        const bool ok = a_ok && kk < C;
+        const uint4 v = *GPTR(const uint4, a_row + (ok ? kk : 0));
+        if (ok) a_frag[i] = v;
+      }
     }
   }
   __syncthreads();
@@ -96,9 +104,12 @@ correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int kk = kb + 16 * i + 8 * h;
-            const bool ok = b_ok && kk < C;
-            const uint4 v = *GPTR(const uint4, b_row + (ok ? kk : 0));
-            bv[i] = ok ? v : make_uint4(0, 0, 0, 0);
+            bv[i] = make_uint4(0, 0, 0, 0);
+            if (kb + 16 * i < C) {                                 // block-uniform
+              const bool ok = b_ok && kk < C;
+              const uint4 v = *GPTR(const uint4, b_row + (ok ? kk : 0));
+              if (ok) bv[i] = v;
+            }
           }
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
@@ -138,7 +149,7 @@ correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__
           if (xx >= t * 32 && xx < t * 32 + 32 && xx < W) {
             float v = tile[px][xx - t * 32] * inv_c;
             v = v > 0.f ? v : v * slope;
-            otile[px * DD + dyi * D + r] = (T)v;
+            otile[px * DDp + dyi * D + r] = (T)v;
           }
         }
       }
@@ -147,9 +158,99 @@ correlation_fwd_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__
   }
   __syncthreads();
   T* o_base = out + (((long)b * H + y) * W + x0) * ldo;
-  for (int e = threadIdx.x; e < 32 * DD; e += 256) {
-    const int px = e / DD, ch = e - px * DD;
-    if (x0 + px < W) *GPTR(T, o_base + (long)px * ldo + ch) = otile[e];
+  // one pixel row per wave pass: 16-byte stores for the full granules (whole cache lines leave per instruction), scalar tail
+  const bool vec = (reinterpret_cast<uintptr_t>(out) % 16) == 0 && (ldo % VEC) == 0;
+  const int full = vec ? DD / VEC : 0;
+  for (int px = wid; px < 32; px += 4) {
+    if (x0 + px >= W) break;
+    T* dst = o_base + (long)px * ldo;
+    const T* src = otile + px * DDp;
+    for (int j = lane; j < full; j += 64) *GPTR(uint4, dst + j * VEC) = *reinterpret_cast<const uint4*>(src + j * VEC);
+    for (int ch = full * VEC + lane; ch < DD; ch += 64) *GPTR(T, dst + ch) = src[ch];
+  }
+}
+
+// ---- vector-ALU forward for the few-channel, few-displacement cost volumes (PWC: 32..196 channels, 81 displacements) --------
+// With C = 32 a 32x32xC MFMA tile is two instructions of useful work per staged row while the band extraction, the per-tile
+// loads and the block bookkeeping stay the same: the MFMA kernel above takes 217 us for PWC's level 2 (57 MB in and out).  Here a
+// block owns one output row and 64 pixels: the f1 row segment sits in LDS, the f2 row of each displacement row is staged next to it
+// (zero outside the image), and every (pixel, dx) pair is one dot product over the channel granules (v_dot2_f32_bf16 / fma) read
+// as 16-byte LDS vectors; results collect in an LDS output tile that leaves as whole rows.  LDS rows are padded by one granule.
+__device__ __forceinline__ float dot_granule(const uint4 a, const uint4 b, float acc, __bf16) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a.x), __builtin_bit_cast(bf2_t, b.x), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a.y), __builtin_bit_cast(bf2_t, b.y), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a.z), __builtin_bit_cast(bf2_t, b.z), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a.w), __builtin_bit_cast(bf2_t, b.w), acc, false);
+  return acc;
+}
+__device__ __forceinline__ float dot_granule(const uint4 a, const uint4 b, float acc, float) {
+  acc = fmaf(__uint_as_float(a.x), __uint_as_float(b.x), acc);
+  acc = fmaf(__uint_as_float(a.y), __uint_as_float(b.y), acc);
+  acc = fmaf(__uint_as_float(a.z), __uint_as_float(b.z), acc);
+  acc = fmaf(__uint_as_float(a.w), __uint_as_float(b.w), acc);
+  return acc;
+}
+
+constexpr int kCorrXT = 64;                                          // output pixels per block of the vector-ALU kernel
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+correlation_fwd_valu_kernel(const T* __restrict__ f1, long ld1, const T* __restrict__ f2, long ld2, T* __restrict__ out, long ldo,
+                            int B, int H, int W, int C, int c_norm, int R, int s2, float slope) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  constexpr int VEC = 16 / (int)sizeof(T), XT = kCorrXT;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int D = 2 * R + 1, DD = D * D, DDp = (DD + VEC - 1) / VEC * VEC;
+  const int G = C / VEC, GS = G + 1, XW = XT + 2 * R * s2;
+  uint4* at = reinterpret_cast<uint4*>(dyn);                        // [XT][GS]  f1 row segment
+  uint4* bt = at + XT * GS;                                          // [XW][GS]  f2 row of the current displacement row
+  T* otile = reinterpret_cast<T*>(bt + XW * GS);                    // [XT][DDp]
+  const int xt = (W + XT - 1) / XT;
+  const int u = blockIdx.x;
+  const int x0 = (u % xt) * XT, y = (u / xt) % H, b = u / (xt * H);
+  const float inv_c = 1.f / (float)c_norm;
+  const T* row1 = f1 + (((long)b * H + y) * W) * ld1;
+  for (int e = threadIdx.x; e < XT * G; e += 256) {
+    const int px = e / G, gq = e - px * G, x = x0 + px;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (x < W) v = *GPTR(const uint4, row1 + (long)x * ld1 + gq * VEC);
+    at[px * GS + gq] = v;
+  }
+  for (int e = threadIdx.x; e < XT * DDp / VEC; e += 256) reinterpret_cast<uint4*>(otile)[e] = make_uint4(0, 0, 0, 0);
+  for (int dyi = 0; dyi < D; ++dyi) {
+    const int yy = y + (dyi - R) * s2;
+    if (yy < 0 || yy >= H) continue;                                 // block-uniform: that displacement row stays zero
+    __syncthreads();                                                 // the previous row's dot products are done with bt
+    const T* row2 = f2 + (((long)b * H + yy) * W) * ld2;
+    for (int e = threadIdx.x; e < XW * G; e += 256) {
+      const int kk = e / G, gq = e - kk * G, x = x0 - R * s2 + kk;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (x >= 0 && x < W) v = *GPTR(const uint4, row2 + (long)x * ld2 + gq * VEC);
+      bt[kk * GS + gq] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < XT * D; i += 256) {
+      const int px = i / D, dxi = i - px * D;                       // f2 pixel x0 + px + (dxi - R) s2 = staged column px + dxi s2
+      const uint4* pa = at + px * GS;
+      const uint4* pb = bt + (px + dxi * s2) * GS;
+      float acc = 0.f;
+      for (int gq = 0; gq < G; ++gq) acc = dot_granule(pa[gq], pb[gq], acc, T());
+      float v = acc * inv_c;
+      v = v > 0.f ? v : v * slope;
+      otile[px * DDp + dyi * D + dxi] = (T)v;
+    }
+  }
+  __syncthreads();
+  T* o_base = out + (((long)b * H + y) * W + x0) * ldo;
+  const bool vec = (reinterpret_cast<uintptr_t>(out) % 16) == 0 && (ldo % VEC) == 0;
+  const int full = vec ? DD / VEC : 0;
+  for (int px = wid; px < XT; px += 4) {
+    if (x0 + px >= W) break;
+    T* dst = o_base + (long)px * ldo;
+    const T* src = otile + px * DDp;
+    for (int j = lane; j < full; j += 64) *GPTR(uint4, dst + j * VEC) = *reinterpret_cast<const uint4*>(src + j * VEC);
+    for (int ch = full * VEC + lane; ch < DD; ch += 64) *GPTR(T, dst + ch) = src[ch];
   }
 }
 
@@ -276,22 +377,28 @@ correlation_bwd_mfma_kernel(const __bf16* __restrict__ g, long ldg, const __bf16
     const __bf16* frow = fo + (((long)b * H + yy) * W) * ldo_;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int e = threadIdx.x + 256 * i;
-      const int kk = e / cgran, cg = e - kk * cgran, k = klo + kk;
-      const bool ok = e < KW * cgran && k < W && cg * 8 < C;
-      const uint4 v = *GPTR(const uint4, frow + (long)(ok ? k : 0) * ldo_ + (ok ? cg * 8 : 0));
-      breg[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+      breg[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (256 * i < KW * cgran) {                                   // block-uniform: few-channel levels fill 1..3 of the 14 slots
+        const int e = threadIdx.x + 256 * i;
+        const int kk = e / cgran, cg = e - kk * cgran, k = klo + kk;
+        const bool ok = e < KW * cgran && k < W && cg * 8 < C;
+        const uint4 v = *GPTR(const uint4, frow + (long)(ok ? k : 0) * ldo_ + (ok ? cg * 8 : 0));
+        if (ok) breg[i] = v;
+      }
     }
     const int gy = WHICH == 0 ? y : yy;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int e = threadIdx.x + 256 * i;
-      const int m = e / D, dxi = e - m * D, xm = x0 + m;
-      const int k = WHICH == 0 ? xm + (dxi - R) * s2 : xm - (dxi - R) * s2;     // the other map's pixel this entry pairs with
-      const bool ok = e < 32 * D && xm < W && k >= 0 && k < W;
-      const int gx = WHICH == 0 ? xm : k;
-      const __bf16 v = *GPTR(const __bf16, g + (((long)b * H + gy) * W + (ok ? gx : 0)) * ldg + (ok ? dyi * D + dxi : 0));
-      areg[i] = ok ? v : (__bf16)0.f;
+      areg[i] = (__bf16)0.f;
+      if (256 * i < 32 * D) {                                       // block-uniform
+        const int e = threadIdx.x + 256 * i;
+        const int m = e / D, dxi = e - m * D, xm = x0 + m;
+        const int k = WHICH == 0 ? xm + (dxi - R) * s2 : xm - (dxi - R) * s2;   // the other map's pixel this entry pairs with
+        const bool ok = e < 32 * D && xm < W && k >= 0 && k < W;
+        const int gx = WHICH == 0 ? xm : k;
+        const __bf16 v = *GPTR(const __bf16, g + (((long)b * H + gy) * W + (ok ? gx : 0)) * ldg + (ok ? dyi * D + dxi : 0));
+        if (ok) areg[i] = v;
+      }
     }
   };
   auto commit = [&]() {                                            // registers -> LDS tiles
@@ -346,6 +453,83 @@ correlation_bwd_mfma_kernel(const __bf16* __restrict__ g, long ldg, const __bf16
       if (accumulate) v += ldf(d);
       stf(d, v);
     }
+  }
+}
+
+// ---- vector-ALU backward for PWC's cost volumes (81 displacements, up to 128 channels) ------------------------------------------
+// One thread per (output pixel, 16-byte channel granule), XT = floor(256 / granules) pixels per block; per displacement row the other
+// map's row segment (and, for dF2, that row's gradient entries) is staged in LDS, and every (dy, dx) adds  g * granule  to the
+// thread's fp32 accumulators.  Same sums as the kernels above (fp32 accumulate, fixed order dy-major), one 16-byte store per thread.
+template <typename T, int WHICH>
+__global__ void __launch_bounds__(256)
+correlation_bwd_valu_kernel(const T* __restrict__ g, long ldg, const T* __restrict__ fo, long ldo_, T* __restrict__ dout, long ldd,
+                            int B, int H, int W, int C, int c_norm, int R, int s2, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int D = 2 * R + 1, DD = D * D;
+  const int G = C / VEC, XT = 256 / G, XW = XT + 2 * R * s2, GS = G + 1;
+  uint4* bt = reinterpret_cast<uint4*>(dyn);                        // [XW][GS]  the other map's row segment
+  T* gt = reinterpret_cast<T*>(bt + XW * GS);                       // WHICH 0: [XT][DD] own gradient rows; WHICH 1: [XW][D] entries of row dyi
+  const int xt = (W + XT - 1) / XT;
+  const int u = blockIdx.x;
+  const int x0 = (u % xt) * XT, y = (u / xt) % H, b = u / (xt * H);
+  const int px = min(threadIdx.x / G, XT - 1), gq = threadIdx.x - (threadIdx.x / G) * G;
+  const bool active = threadIdx.x < XT * G;                         // 256 is not a multiple of every granule count
+  const float inv_c = 1.f / (float)c_norm;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  if (WHICH == 0) {
+    const T* grow = g + (((long)b * H + y) * W) * ldg;
+    for (int e = threadIdx.x; e < XT * DD; e += 256) {
+      const int p = e / DD, ch = e - p * DD;
+      gt[e] = x0 + p < W ? *GPTR(const T, grow + (long)(x0 + p) * ldg + ch) : (T)0.f;
+    }
+  }
+  for (int dyi = 0; dyi < D; ++dyi) {
+    const int yy = WHICH == 0 ? y + (dyi - R) * s2 : y - (dyi - R) * s2;
+    if (yy < 0 || yy >= H) continue;                                 // block-uniform
+    __syncthreads();
+    const T* frow = fo + (((long)b * H + yy) * W) * ldo_;
+    for (int e = threadIdx.x; e < XW * G; e += 256) {
+      const int kk = e / G, q = e - kk * G, x = x0 - R * s2 + kk;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (x >= 0 && x < W) v = *GPTR(const uint4, frow + (long)x * ldo_ + q * VEC);
+      bt[kk * GS + q] = v;
+    }
+    if (WHICH == 1) {
+      const T* grow = g + (((long)b * H + yy) * W) * ldg + dyi * D;
+      for (int e = threadIdx.x; e < XW * D; e += 256) {
+        const int kk = e / D, dxi = e - kk * D, x = x0 - R * s2 + kk;
+        gt[e] = (x >= 0 && x < W) ? *GPTR(const T, grow + (long)x * ldg + dxi) : (T)0.f;
+      }
+    }
+    __syncthreads();
+    for (int dxi = 0; dxi < D; ++dxi) {
+      // dF1: pairs with f2 pixel x + (dxi - R) s2 = staged column px + dxi s2;  dF2: source pixel x - (dxi - R) s2 = column px + (2R - dxi) s2
+      const int col = WHICH == 0 ? px + dxi * s2 : px + (2 * R - dxi) * s2;
+      const float gv = (float)(WHICH == 0 ? gt[px * DD + dyi * D + dxi] : gt[col * D + dxi]);
+      const uint4 v = bt[col * GS + gq];
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[2 * i] = fmaf(gv, __uint_as_float(w[i] << 16), acc[2 * i]);
+          acc[2 * i + 1] = fmaf(gv, __uint_as_float(w[i] & 0xffff0000u), acc[2 * i + 1]);
+        }
+      } else {
+        acc[0] = fmaf(gv, __uint_as_float(v.x), acc[0]); acc[1] = fmaf(gv, __uint_as_float(v.y), acc[1]);
+        acc[2] = fmaf(gv, __uint_as_float(v.z), acc[2]); acc[3] = fmaf(gv, __uint_as_float(v.w), acc[3]);
+      }
+    }
+  }
+  if (!active || x0 + px >= W) return;
+  T* d = dout + (((long)b * H + y) * W + x0 + px) * ldd + gq * VEC;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    float v = acc[e] * inv_c;
+    if (accumulate) v += ldf(d + e);
+    stf(d + e, v);
   }
 }
 
@@ -696,7 +880,25 @@ int mireg_correlation_fwd(const void* f1, long ld1, const void* f2, long ld2, vo
   const long g = units;
   const int R = max_displacement / stride2;
   const int DD = (2 * R + 1) * (2 * R + 1);
-  const size_t lds = 4 * 32 * 33 * 4 + (size_t)32 * DD * (dtype == MIREG_DTYPE_BF16 ? 2 : 4);
+  const int DDp = (DD + V - 1) / V * V;                             // output tile rows padded to 16 bytes
+  // few channels and few displacements (PWC's levels): dot products on the vector ALUs; the MFMA formulation wins from
+  // 64 channels up (scratch/mb_corr_levels.py, profiles/README.md); MIREG_CORR_VALU=0/1 forces one for A/B runs
+  static const int force = getenv("MIREG_CORR_VALU") ? atoi(getenv("MIREG_CORR_VALU")) : -1;
+  const size_t esz = dtype == MIREG_DTYPE_BF16 ? 2 : 4;
+  const size_t lds_valu = ((size_t)(kCorrXT + kCorrXT + 2 * R * stride2) * (C / V + 1)) * 16 + (size_t)kCorrXT * DDp * esz;
+  const bool valu = force >= 0 ? force == 1 : (C <= 32 && DD <= 81);
+  if (valu && lds_valu <= 160 * 1024 - 1024 && (dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32)) {
+    const long gv = (long)B * H * ((W + kCorrXT - 1) / kCorrXT);
+    if (dtype == MIREG_DTYPE_BF16) {
+      if (lds_valu > 48 * 1024) (void)hipFuncSetAttribute((const void*)correlation_fwd_valu_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_valu);
+      hipLaunchKernelGGL((correlation_fwd_valu_kernel<__bf16>), dim3((unsigned)gv), dim3(256), lds_valu, stream, (const __bf16*)f1, ld1, (const __bf16*)f2, ld2, (__bf16*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
+    } else {
+      if (lds_valu > 48 * 1024) (void)hipFuncSetAttribute((const void*)correlation_fwd_valu_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_valu);
+      hipLaunchKernelGGL((correlation_fwd_valu_kernel<float>), dim3((unsigned)gv), dim3(256), lds_valu, stream, (const float*)f1, ld1, (const float*)f2, ld2, (float*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
+    }
+    MIREG_LAUNCH_RET();
+  }
+  const size_t lds = 4 * 32 * 33 * 4 + (size_t)32 * DDp * (dtype == MIREG_DTYPE_BF16 ? 2 : 4);
   if (dtype == MIREG_DTYPE_BF16)
     hipLaunchKernelGGL((correlation_fwd_kernel<__bf16>), dim3((unsigned)g), dim3(256), lds, stream, (const __bf16*)f1, ld1, (const __bf16*)f2, ld2, (__bf16*)out, ldo, B, H, W, C, c_norm, R, stride2, slope);
   else if (dtype == MIREG_DTYPE_F32)
@@ -714,6 +916,37 @@ int mireg_correlation_bwd(const void* g, long ldg, const void* f1, long ld1, con
   long gr = (units + 3) / 4;
   if (gr > 4096) gr = 4096;
   const int R = max_displacement / stride2;
+  // few channels (PWC level 2): one thread per (pixel, channel granule) on the vector ALUs (see correlation_fwd_valu_kernel)
+  {
+    static const int force = getenv("MIREG_CORR_VALU") ? atoi(getenv("MIREG_CORR_VALU")) : -1;
+    const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4, D = 2 * R + 1;
+    const int G = C % V == 0 ? C / V : 0;
+    const bool shape_ok = G > 0 && G <= 32 && ld1 % V == 0 && ld2 % V == 0 && (uintptr_t)f1 % 16 == 0 && (uintptr_t)f2 % 16 == 0 &&
+                          (!df1 || (ldd1 % V == 0 && (uintptr_t)df1 % 16 == 0)) && (!df2 || (ldd2 % V == 0 && (uintptr_t)df2 % 16 == 0)) &&
+                          (dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
+    const bool valu = shape_ok && (force >= 0 ? force == 1 : (C <= 128 && D * D <= 81));    // measured: wins up to 128 channels, 256 loses 2x
+    if (valu) {
+      const int XT = 256 / G, XW = XT + 2 * R * stride2;
+      const size_t esz = dtype == MIREG_DTYPE_BF16 ? 2 : 4;
+      const size_t lds0 = (size_t)XW * (G + 1) * 16 + (size_t)XT * D * D * esz, lds1 = (size_t)XW * (G + 1) * 16 + (size_t)XW * D * esz;
+      const long gv = (long)B * H * ((W + XT - 1) / XT);
+      if (lds0 <= 150 * 1024 && lds1 <= 150 * 1024 && gv < (1L << 30)) {
+#define MIREG_CORR_BWD_VALU(T, WHICH, fo_, ldo__, dd, lddd, acc_, lds_) { \
+          if (lds_ > 48 * 1024) (void)hipFuncSetAttribute((const void*)correlation_bwd_valu_kernel<T, WHICH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+          hipLaunchKernelGGL((correlation_bwd_valu_kernel<T, WHICH>), dim3((unsigned)gv), dim3(256), lds_, stream, (const T*)g, ldg, (const T*)fo_, ldo__, \
+                             (T*)dd, lddd, B, H, W, C, c_norm, R, stride2, acc_); }
+        if (dtype == MIREG_DTYPE_BF16) {
+          if (df1) MIREG_CORR_BWD_VALU(__bf16, 0, f2, ld2, df1, ldd1, accumulate1, lds0)
+          if (df2) MIREG_CORR_BWD_VALU(__bf16, 1, f1, ld1, df2, ldd2, accumulate2, lds1)
+        } else {
+          if (df1) MIREG_CORR_BWD_VALU(float, 0, f2, ld2, df1, ldd1, accumulate1, lds0)
+          if (df2) MIREG_CORR_BWD_VALU(float, 1, f1, ld1, df2, ldd2, accumulate2, lds1)
+        }
+#undef MIREG_CORR_BWD_VALU
+        MIREG_LAUNCH_RET();
+      }
+    }
+  }
   // bf16 with 16-byte aligned channel rows: bf16 matrix cores + LDS-staged operands
   if (dtype == MIREG_DTYPE_BF16 && C <= 512 && C % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && (uintptr_t)f1 % 16 == 0 && (uintptr_t)f2 % 16 == 0 &&
       (uintptr_t)g % 2 == 0 && units < (1L << 30)) {

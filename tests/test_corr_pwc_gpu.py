@@ -44,6 +44,32 @@ def test_correlation_bf16_views_with_lrelu():
     assert float(out.slice(0, 32).nchw().abs().max()) == 0.0      # neighbours of the slice untouched
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [(4, 1, 32, 64, 64, 2), (4, 1, 32, 20, 72, 1), (2, 1, 16, 9, 33, 3), (4, 1, 8, 7, 130, 1)])
+def test_correlation_few_channel_kernel(cfg, prec):
+    """The vector-ALU forward (<= 32 channels, <= 81 displacements: PWC level 2) against the published-definition oracle, written
+    into a channel slice of a wider buffer (ragged widths, more than one 64-pixel block per row)."""
+    from mireg.correlation import correlation_views
+    from mireg.engine import Workspace
+    md, s2, C, H, W, B = cfg
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    ws = Workspace(torch.device(DEV), dt)
+    f1 = nets.analytic_input((B, C, H, W), seed=1) - 0.5
+    f2 = nets.analytic_input((B, C, H, W), seed=2) - 0.5
+    if prec == "bf16":
+        f1, f2 = f1.bfloat16().float(), f2.bfloat16().float()
+    D = 2 * (md // s2) + 1
+    want = torch.nn.functional.leaky_relu(oops.correlation(f1, f2, md, 1, md, 1, s2, 1), 0.1)
+    v1, v2 = ws.new(B, H, W, C), ws.new(B, H, W, C)
+    v1.buf[..., :C] = f1.permute(0, 2, 3, 1).to(DEV)
+    v2.buf[..., :C] = f2.permute(0, 2, 3, 1).to(DEV)
+    out = ws.new(B, H, W, 16 + D * D + 5)
+    out.buf.fill_(7.0)
+    correlation_views(v1, v2, out.slice(16, D * D), C, md, s2, 0.1, ws.code)
+    assert _rel(out.slice(16, D * D).nchw().float(), want) < (2e-5 if prec == "fp32" else 1e-2)
+    assert float((out.slice(0, 16).nchw().float() - 7.0).abs().max()) == 0.0 and float((out.slice(16 + D * D, 5).nchw().float() - 7.0).abs().max()) == 0.0
+
+
 def test_pwc_warp_golden(golden):
     from mireg.correlation import pwc_warp_views
     from mireg.engine import Workspace
@@ -124,7 +150,9 @@ def test_correlation_backward_vs_autograd():
     for prec, tol in (("fp32", 3e-5), ("bf16", 2e-2)):
         dt = torch.float32 if prec == "fp32" else torch.bfloat16
         ws = Workspace(torch.device(DEV), dt)
-        for (md, s2, C, H, W, B) in ((20, 2, 256, 32, 32, 1), (4, 1, 96, 16, 40, 2), (4, 1, 200, 4, 4, 2)):
+        # 81 displacements and <= 128 channels take the vector-ALU kernels (PWC), the others the matrix-core ones
+        for (md, s2, C, H, W, B) in ((20, 2, 256, 32, 32, 1), (4, 1, 96, 16, 40, 2), (4, 1, 200, 4, 4, 2), (4, 1, 32, 64, 64, 2),
+                                     (4, 1, 32, 20, 72, 1), (2, 1, 16, 9, 33, 2)):
             f1 = (nets.analytic_input((B, C, H, W), seed=1) - 0.5)
             f2 = (nets.analytic_input((B, C, H, W), seed=2) - 0.5)
             D = 2 * (md // s2) + 1
