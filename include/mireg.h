@@ -319,8 +319,8 @@ int mireg_thin_gather18(const void* dy, long ld_dy, void* dz, long ld_dz, int B,
  * (B, 2Hc, 2Wc, ld_f), two channels each.  bwd_weights writes mireg_tiny_deconv_blocks(B,Hc,Wc) partial slabs in the standard
  * layout [blk][2][16*Cpad] (pad slots untouched: hand in zeroed memory), summed by mireg_wgrad_reduce / mireg_unpack_wgrad. */
 int mireg_tiny_deconv_blocks(int B, int Hc, int Wc);
-int mireg_tiny_deconv_fwd(const void* x_coarse, long ld_c, const float* w, const float* bias, void* y_fine, long ld_f, int B, int Hc,
-                          int Wc, int dtype, hipStream_t stream);
+int mireg_tiny_deconv_fwd(const void* x_coarse, long ld_c, const float* w, const float* bias, void* y_fine, long ld_f, float* y32,
+                          long ld_y32, int B, int Hc, int Wc, int dtype, hipStream_t stream);   /* y_fine and / or an fp32 copy y32 */
 /* dx_coarse = conv_s2(g_fine, w) [+ add_nchw, a planar fp32 (B, 2, Hc, Wc) term such as the loss gradient of that flow; may be
  * NULL] [+ dx_coarse when accumulate] */
 int mireg_tiny_deconv_bwd_data(const void* g_fine, long ld_f, const float* w, void* dx_coarse, long ld_c, int accumulate,

@@ -366,7 +366,7 @@ thin_gather18_kernel(const T* __restrict__ dy, long ld_dy, T* __restrict__ dz, l
 template <typename T>
 __global__ void __launch_bounds__(256)
 tiny_deconv_fwd_kernel(const T* __restrict__ xc, long ld_c, const float* __restrict__ w, const float* __restrict__ bias,
-                       T* __restrict__ yf, long ld_f, int B, int Hc, int Wc_) {
+                       T* __restrict__ yf, long ld_f, float* __restrict__ y32, long ld_32, int B, int Hc, int Wc_) {
   const int Hf = 2 * Hc, Wf = 2 * Wc_;
   const long n = (long)B * Hf * Wf;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
@@ -387,8 +387,8 @@ tiny_deconv_fwd_kernel(const T* __restrict__ xc, long ld_c, const float* __restr
         a1 += c0 * w[(0 * 2 + 1) * 16 + ky * 4 + kx] + c1 * w[(1 * 2 + 1) * 16 + ky * 4 + kx];
       }
     }
-    T* d = yf + p * ld_f;
-    d[0] = (T)a0; d[1] = (T)a1;
+    if (yf) { T* d = yf + p * ld_f; d[0] = (T)a0; d[1] = (T)a1; }
+    if (y32) { float* d = y32 + p * ld_32; d[0] = a0; d[1] = a1; }              // fp32 copy of the flow for the loss tail
   }
 }
 
@@ -578,16 +578,16 @@ int mireg_tiny_deconv_blocks(int B, int Hc, int Wc) {
   return (int)(g < 1 ? 1 : (g > 192 ? 192 : g));       // so it wants blocks, not work per block (slab: 1 KiB per block)
 }
 
-int mireg_tiny_deconv_fwd(const void* x_coarse, long ld_c, const float* w, const float* bias, void* y_fine, long ld_f, int B, int Hc,
-                          int Wc, int dtype, hipStream_t stream) {
-  MIREG_CHECK_ARG(x_coarse && w && y_fine && ld_c >= 2 && ld_f >= 2 && B > 0 && Hc > 0 && Wc > 0);
+int mireg_tiny_deconv_fwd(const void* x_coarse, long ld_c, const float* w, const float* bias, void* y_fine, long ld_f, float* y32,
+                          long ld_y32, int B, int Hc, int Wc, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(x_coarse && w && (y_fine || y32) && ld_c >= 2 && (!y_fine || ld_f >= 2) && (!y32 || ld_y32 >= 2) && B > 0 && Hc > 0 && Wc > 0);
   MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
   const long n = (long)B * Hc * Wc * 4;
   const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   if (dtype == MIREG_DTYPE_BF16)
-    hipLaunchKernelGGL((tiny_deconv_fwd_kernel<__bf16>), dim3(grid), dim3(256), 0, stream, (const __bf16*)x_coarse, ld_c, w, bias, (__bf16*)y_fine, ld_f, B, Hc, Wc);
+    hipLaunchKernelGGL((tiny_deconv_fwd_kernel<__bf16>), dim3(grid), dim3(256), 0, stream, (const __bf16*)x_coarse, ld_c, w, bias, (__bf16*)y_fine, ld_f, y32, ld_y32, B, Hc, Wc);
   else
-    hipLaunchKernelGGL((tiny_deconv_fwd_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)x_coarse, ld_c, w, bias, (float*)y_fine, ld_f, B, Hc, Wc);
+    hipLaunchKernelGGL((tiny_deconv_fwd_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)x_coarse, ld_c, w, bias, (float*)y_fine, ld_f, y32, ld_y32, B, Hc, Wc);
   MIREG_LAUNCH_RET();
 }
 

@@ -531,9 +531,11 @@ class ConvLayer:
         (only exact divisions contribute).  out has the LARGER spatial size."""
         assert g.C <= self.Cop and g.c0 + self.Cop <= g.ld, (self.name, g.C, self.Co, g.ld)
         o = out if out is not None else y32
-        if self.tiny and (TINY_MASK & 1) and out is not None and y32 is None and slope == 1.0 and not accumulate and (out.H, out.W) == (2 * g.H, 2 * g.W):
+        if self.tiny and (TINY_MASK & 1) and o is not None and slope == 1.0 and not accumulate and (o.H, o.W) == (2 * g.H, 2 * g.W):
             _lib.call("mireg_tiny_deconv_fwd", g.ptr, g.ld, self.weight.data_ptr(),
-                      self.bias.data_ptr() if (bias and self.bias is not None) else None, out.ptr, out.ld, g.B, g.H, g.W,
+                      self.bias.data_ptr() if (bias and self.bias is not None) else None,
+                      out.ptr if out is not None else None, out.ld if out is not None else 0,
+                      y32.ptr if y32 is not None else None, y32.ld if y32 is not None else 0, g.B, g.H, g.W,
                       self.ws.code, _stream())
             return
         if self.thin and out is not None and y32 is None and slope == 1.0 and not bias:

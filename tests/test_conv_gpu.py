@@ -157,8 +157,13 @@ def test_tiny_upsampler_kernels(prec):
             run_pack(lay.pack_jobs(), ws.code, DEV)
             xv, gv = _view_from(x.to(DEV), ws), _view_from(cot.to(DEV), ws)
             yv = ws.new(B, 2 * H, 2 * W, 2)
-            lay.run_dgrad_form(xv, yv, bias=True)
+            y32v = ws.new(B, 2 * H, 2 * W, 2, dtype=torch.float32, pad=2)
+            lay.run_dgrad_form(xv, yv, y32=y32v, bias=True)
             assert _rel(yv.nchw().float(), y_ref.detach()) < tol, "forward"
+            assert _rel(y32v.nchw(), y_ref.detach()) < min(tol, 1e-4) or prec == "bf16", "forward, fp32 copy"
+            assert _rel(y32v.nchw(), y_ref.detach()) < tol
+            lay.run_dgrad_form(xv, None, y32=y32v, bias=True)                      # fp32 copy only (PWC's flow0)
+            assert _rel(y32v.nchw(), y_ref.detach()) < tol
             dxv = ws.new(B, H, W, 2)
             assert lay.tiny_bwd_data_ok(gv, dxv)
             lay.run_fwd_form(gv, dxv, bias=False)
