@@ -642,7 +642,9 @@ class ConvLayer:
             cands += [(sp, 2) for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if sp <= max(dy.rows // 512, 1) and 96 <= tiles * sp <= 1536]
         if WGRAD_ALGO != 2:
             tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
-            cands += [(sp, 1) for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32, 44, 64, 96, 128, 192)
+            # one- and two-tile launches (PWC's 16- and 32-channel pyramid layers over 128x128 maps) get all their parallelism from
+            # the pixel split: up to 768 ways
+            cands += [(sp, 1) for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32, 44, 64, 96, 128, 192, 256, 384, 512, 768)
                       if sp <= max(nk // 8, 1) and 128 <= tiles * sp <= 2304]
         cands = [c for c in cands if c[0] * elems <= (1 << 26)] or [(self.wgrad_split, self.wgrad_algo)]
         tmp = torch.empty(max(c[0] for c in cands) * elems, device=self.ws.device, dtype=F32)
