@@ -119,6 +119,10 @@ int mireg_resize_trilinear_fwd(const float* in, long isn, long isc, long isp, fl
                                int d, int h, int w, int align_corners, hipStream_t stream);
 int mireg_resize_trilinear_bwd(const float* gout, float* gin, long isn, long isc, long isp, int N, int C, int D, int H, int W,
                                int d, int h, int w, int align_corners, float beta, hipStream_t stream);
+/* the same adjoint as three 1-D passes (x, y, z) through a caller-owned workspace of N*C*d*h*W + N*C*d*H*W floats: reads the
+ * fine gradient once, contiguously (sums in another order than the direct kernel: equal to fp32 rounding) */
+int mireg_resize_trilinear_bwd_sep(const float* gout, float* gin, long isn, long isc, long isp, int N, int C, int D, int H, int W,
+                                   int d, int h, int w, int align_corners, float beta, float* ws, long ws_elems, hipStream_t stream);
 int mireg_stn3d_fwd(const float* flow, long fsb, long fsc, long fsp, const float* frame, float* warped, int B, int C, int d,
                     int h, int w, hipStream_t stream);
 int mireg_stn3d_bwd(const float* flow, long fsb, long fsc, long fsp, const float* frame, const float* gout, float* gflow,

@@ -103,6 +103,37 @@ resize3d_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, lon
   }
 }
 
+// Separable form of the same backward: trilinear interpolation is three 1-D linear interpolations, so its adjoint is three 1-D
+// gathers (x, then y, then z).  The direct kernel above visits up to 8 x 8 x 8 output voxels per source voxel with a 16-byte lane
+// stride (x4 upsampling of the 3-channel flow: 0.6-1.0 ms for 8 x 3 x 128^3 gradients); the passes below read the big tensor once,
+// contiguously, and shrink it 4x per pass.  src / dst are [outer][L][inner] planes; the last pass writes through the strided
+// (batch, channel, voxel) addressing of gin and applies beta.
+__global__ void __launch_bounds__(kThreads)
+resize1d_bwd_kernel(const float* __restrict__ src, float* __restrict__ dst, long outer, int Lout, int Lin, long inner, float scale,
+                    int align, int strided, long isn, long isc, long isp, int C, float beta) {
+  const long total = outer * Lin * inner;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long in_ = i % inner, o = i / (inner * Lin);
+    const int P = (int)((i / inner) % Lin);
+    int lo, hi;
+    out_range(P, scale, align, Lout, lo, hi);
+    const float* s = src + (o * Lout) * inner + in_;
+    float acc = 0.f;
+    for (int q = lo; q <= hi; ++q) {
+      int q0, q1; float l;
+      src_coord(q, scale, align, Lin, q0, q1, l);
+      const float wq = (q0 == P ? 1.f - l : 0.f) + (q1 == P ? l : 0.f);
+      if (wq != 0.f) acc += wq * s[(long)q * inner];
+    }
+    if (!strided) dst[i] = acc;
+    else {
+      const long n = o / C, c = o - n * C;
+      float* d = dst + n * isn + c * isc + ((long)P * inner + in_) * isp;
+      *d = beta != 0.f ? *d * beta + acc : acc;
+    }
+  }
+}
+
 // ---- dense 3-D warp ---------------------------------------------------------------------------------------------------
 // sampling coordinate per axis, same fp32 op order as the 2-D path: g = (i + f) * (2/n) - 1; p = ((g + 1)/2) * (n - 1)
 __device__ __forceinline__ float stn_coord(float pix, float disp, float two_over, float sizem1) {
@@ -297,6 +328,22 @@ int mireg_resize_trilinear_bwd(const float* gout, float* gin, long isn, long isc
   hipLaunchKernelGGL(resize3d_bwd_kernel, dim3(grid_for((long)N * C * D * H * W)), dim3(kThreads), 0, stream, gout, gin, isn, isc,
                      isp, N, C, D, H, W, d, h, w, host_scale(D, d, align_corners), host_scale(H, h, align_corners),
                      host_scale(W, w, align_corners), align_corners, beta);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_resize_trilinear_bwd_sep(const float* gout, float* gin, long isn, long isc, long isp, int N, int C, int D, int H, int W,
+                                   int d, int h, int w, int align_corners, float beta, float* ws, long ws_elems, hipStream_t stream) {
+  MIREG_CHECK_ARG(gout && gin && ws && N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && d > 0 && h > 0 && w > 0);
+  const long nc = (long)N * C, e1 = nc * d * h * W, e2 = nc * d * H * W;
+  MIREG_CHECK_ARG(ws_elems >= e1 + e2);
+  float* t1 = ws;                                                    // [N*C*d*h][W]
+  float* t2 = ws + e1;                                               // [N*C*d][H][W]
+  hipLaunchKernelGGL(resize1d_bwd_kernel, dim3(grid_for(e1)), dim3(kThreads), 0, stream, gout, t1, nc * d * h, w, W, 1L,
+                     host_scale(W, w, align_corners), align_corners, 0, 0L, 0L, 0L, C, 0.f);
+  hipLaunchKernelGGL(resize1d_bwd_kernel, dim3(grid_for(e2)), dim3(kThreads), 0, stream, (const float*)t1, t2, nc * d, h, H, (long)W,
+                     host_scale(H, h, align_corners), align_corners, 0, 0L, 0L, 0L, C, 0.f);
+  hipLaunchKernelGGL(resize1d_bwd_kernel, dim3(grid_for(nc * D * H * W)), dim3(kThreads), 0, stream, (const float*)t2, gin, nc, d, D,
+                     (long)H * W, host_scale(D, d, align_corners), align_corners, 1, isn, isc, isp, C, beta);
   MIREG_LAUNCH_RET();
 }
 

@@ -42,8 +42,9 @@ class _Resize3dFn(torch.autograd.Function):
         N, C, D, H, W, d, h, w, align = ctx.shape
         g = g.contiguous()
         gin = torch.empty(N, C, D, H, W, device=g.device, dtype=F32)
-        _lib.call("mireg_resize_trilinear_bwd", g.data_ptr(), gin.data_ptr(), C * D * H * W, D * H * W, 1, N, C, D, H, W, d, h, w,
-                  int(align), 0.0, _stream())
+        ws = torch.empty(N * C * d * (h * W + H * W), device=g.device, dtype=F32)       # the two intermediate planes of the separable adjoint
+        _lib.call("mireg_resize_trilinear_bwd_sep", g.data_ptr(), gin.data_ptr(), C * D * H * W, D * H * W, 1, N, C, D, H, W, d, h, w,
+                  int(align), 0.0, ws.data_ptr(), ws.numel(), _stream())
         return gin, None, None
 
 
