@@ -65,6 +65,7 @@ struct ThinArgs {
   void* dx; long ld_dx;           // dgrad output
   float* slab;                    // wgrad partial slabs [tiles][CO][TAPS*Cpad]
   int B, H, W, Cpad, accumulate, ppl;
+  int tpp;                        // dgrad: threads sharing one pixel's dy loads
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
@@ -195,20 +196,17 @@ __global__ void __launch_bounds__(256) thin_dgrad_kernel(const ThinArgs a) {
     }
     __syncthreads();
   }
-  const long NP = (long)a.B * a.H * a.W, total = NP * nchunk;
+  // a.tpp threads share a pixel: each loads the pixel's nine (dy0, dy1) pairs once and walks the channel granules c0, c0 + tpp, ...
+  // with them (the loads are the latency chain of this kernel; one granule per thread re-loaded them for every granule)
+  const int tpp = a.tpp;
+  const long NP = (long)a.B * a.H * a.W, total = NP * tpp;
   const T* dy = reinterpret_cast<const T*>(a.t);
   T* dx = reinterpret_cast<T*>(a.dx);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / nchunk;
-    const int c = (int)(i - p * nchunk);
+    const long p = i / tpp;
+    const int c0 = (int)(i - p * tpp);
+    if (c0 >= nchunk) continue;
     const int b = (int)(p / ((long)a.H * a.W)), r = (int)(p - (long)b * a.H * a.W), y = r / a.W, xx = r - y * a.W;
-    float acc[V];
-    T* out = dx + p * a.ld_dx + c * V;
-    if (a.accumulate) unpack16(*GPTR(const uint4, out), acc, T());
-    else {
-#pragma unroll
-      for (int e = 0; e < V; ++e) acc[e] = 0.f;
-    }
     decltype(ld_pair(dy, true)) g[TAPS];
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {                              // nine (dy0, dy1) pairs in flight, branch-free
@@ -216,9 +214,18 @@ __global__ void __launch_bounds__(256) thin_dgrad_kernel(const ThinArgs a) {
       const bool ok = (unsigned)qy < (unsigned)a.H && (unsigned)qx < (unsigned)a.W;
       g[tap] = ld_pair(dy + (((long)b * a.H + (ok ? qy : y)) * a.W + (ok ? qx : xx)) * a.ld_t, ok);
     }
+    for (int c = c0; c < nchunk; c += tpp) {
+      float acc[V];
+      T* out = dx + p * a.ld_dx + c * V;
+      if (a.accumulate) unpack16(*GPTR(const uint4, out), acc, T());
+      else {
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) dgrad_tap(g[tap], wl + ((long)tap * nchunk + c) * 2, acc);
-    *GPTR(uint4, out) = pack16(acc, T());
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+      }
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) dgrad_tap(g[tap], wl + ((long)tap * nchunk + c) * 2, acc);
+      *GPTR(uint4, out) = pack16(acc, T());
+    }
   }
 }
 
@@ -504,7 +511,13 @@ int mireg_thin_conv_dgrad(const void* dy, long ld_dy, const void* w, long ld_w, 
   a.w = w; a.ld_w = ld_w; a.t = dy; a.ld_t = ld_dy; a.dx = dx; a.ld_dx = ld_dx; a.accumulate = accumulate;
   a.B = B; a.H = H; a.W = W; a.Cpad = Cpad;
   const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4;
-  const long total = (long)B * H * W * (Cpad / V);
+  // threads per pixel: 8 share the dy loads on the big levels; small levels (few pixels, many channels) spread the granules
+  // over more threads instead, down to one granule per thread
+  int tpp = 8;
+  while ((long)B * H * W * tpp < 65536 && tpp < Cpad / V) tpp *= 2;
+  if (tpp > Cpad / V) tpp = Cpad / V;
+  a.tpp = tpp;
+  const long total = (long)B * H * W * tpp;
   const size_t lds = (size_t)CO * TAPS * Cpad * (dtype == MIREG_DTYPE_BF16 ? 2 : 4);
   // latency-bound (nine dependent dy loads per item): as many resident blocks per CU as the weight tile in LDS allows
   const long per_cu = lds + 1024 > 160 * 1024 / 8 ? (long)(160 * 1024 / (lds + 1024)) : 8;
