@@ -69,9 +69,12 @@ def test_flownets_step_batch24_256_graph_autotune_vs_oracle(prec):
             assert err <= 1e-4 * max(1.0, scale) + 4 * noise[i], (i, err, scale, noise[i])
         for a, b in zip(got[0][1], ref[0][1]):
             assert abs(a - b) <= 2e-5 * abs(b) + 1e-7, (got[0][1], ref[0][1])
-        for k in (1, 2, 3):                              # later steps: Adam moves noise-level-gradient weights by +-lr
+        # later steps: Adam (eps 1e-4) moves every weight whose gradient is at rounding level by +-lr, in a direction that depends
+        # on the summation order, i.e. on the launch shapes the autotuner happened to measure fastest in this run; the
+        # trajectories separate by ~0.2 % of a loss term per step (the smoothness term most: seen 0.05-0.7 % at the third step)
+        for k, tol in ((1, 5e-3), (2, 2e-2), (3, 2e-2)):
             for a, b in zip(got[k][1], ref[k][1]):
-                assert abs(a - b) <= 5e-3 * abs(b) + 1e-6, (k, got[k][1], ref[k][1])
+                assert abs(a - b) <= tol * abs(b) + 1e-6, (k, got[k][1], ref[k][1])
         return
     with torch.no_grad():                                # operand-rounding noise of the oracle
         ob = nets.OpticalFlowReg("flownets")

@@ -30,6 +30,25 @@ def test_resize_trilinear_fwd_bwd(align, src, dst):
     assert (resize_trilinear(xcl, dst, align).cpu() - y.detach()).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("align", [True, False])
+def test_resize_trilinear_backward_direct_and_separable_agree(align):
+    """The two exported adjoints of the trilinear resize (one 3-D gather; three 1-D passes through a workspace) give the same
+    gradient up to fp32 summation order, also through strided (channel-last) destinations and with beta accumulation."""
+    from mireg import _lib
+    from mireg.engine import _stream
+    N, C, (D, H, W), (d, h, w) = 2, 3, (5, 6, 7), (20, 24, 28)
+    g = nets.analytic_input((N, C, d, h, w), seed=7, lo=-1.0, hi=1.0).to(DEV)
+    base = nets.analytic_input((N, D, H, W, C), seed=8).to(DEV)                  # channel-last destination: strides (DHWC, 1, C)
+    a, b = base.clone(), base.clone()
+    ws = torch.empty(N * C * d * (h * W + H * W), device=DEV)
+    args = (C * D * H * W, 1, C, N, C, D, H, W, d, h, w, int(align), 0.5)
+    _lib.call("mireg_resize_trilinear_bwd", g.data_ptr(), a.data_ptr(), *args, _stream())
+    _lib.call("mireg_resize_trilinear_bwd_sep", g.data_ptr(), b.data_ptr(), *args, ws.data_ptr(), ws.numel(), _stream())
+    torch.cuda.synchronize()
+    assert _rel(b.cpu(), a.cpu()) < 2e-6
+    assert not torch.equal(a, base)
+
+
 @pytest.mark.parametrize("size,full", [((6, 9, 7), (6, 9, 7)), ((4, 5, 3), (8, 10, 6)), ((1, 4, 4), (2, 8, 8))])
 def test_stn3d_fwd_bwd(size, full):
     from mireg.volume import stn3d
