@@ -577,7 +577,7 @@ nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, i
 // per-column sums over rows (bias gradients): out[c] (+)= sum_m g[m][c]
 template <typename T>
 __global__ void __launch_bounds__(256)
-colsum_kernel(const T* __restrict__ g, long ld, long M, int C, float* __restrict__ out) {
+colsum_kernel(const T* __restrict__ g, long ld, long M, int C, float* __restrict__ out, float* __restrict__ partial, int accumulate) {
   __shared__ float red[256];
   const int c = blockIdx.x;
   float acc = 0.f;
@@ -585,7 +585,11 @@ colsum_kernel(const T* __restrict__ g, long ld, long M, int C, float* __restrict
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0) atomicAdd(&out[c], red[0]);
+  // no float atomics: row segments go to partial[segment][c] and are summed in order by colsum_finalize_kernel (one segment: direct)
+  if (threadIdx.x == 0) {
+    if (partial) partial[(long)blockIdx.y * C + c] = red[0];
+    else out[c] = accumulate ? out[c] + red[0] : red[0];
+  }
 }
 
 // bias gradient = column sums of dy, deterministic: block = 2 channel granules x one row segment (128 row lanes,
@@ -972,11 +976,15 @@ int mireg_colsum(const void* g, long ld, long M, int C, float* out, int accumula
     if (nseg > 1) hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, nseg, C, out, accumulate);
     MIREG_LAUNCH_RET();
   }
-  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, stream) != hipSuccess) return MIREG_ERR_LAUNCH;
-  long gy = (M + 256 * 16 - 1) / (256 * 16);
-  if (gy > 64) gy = 64;
-  if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((colsum_kernel<__bf16>), dim3(C, (unsigned)gy), dim3(256), 0, stream, (const __bf16*)g, ld, M, C, out);
-  else hipLaunchKernelGGL((colsum_kernel<float>), dim3(C, (unsigned)gy), dim3(256), 0, stream, (const float*)g, ld, M, C, out);
+  // channel counts that are not a granule multiple (the 2-channel heads and upsamplers): one block column per channel, row segments
+  // through the workspace and a fixed-order finalize (deterministic; without a workspace a single segment per channel)
+  long gy = workspace ? (M + 256 * 16 - 1) / (256 * 16) : 1;
+  if (gy > MIREG_COLSUM_MAX_SEGMENTS) gy = MIREG_COLSUM_MAX_SEGMENTS;
+  if (gy < 1) gy = 1;
+  float* partial = gy > 1 ? workspace : nullptr;
+  if (dtype == MIREG_DTYPE_BF16) hipLaunchKernelGGL((colsum_kernel<__bf16>), dim3(C, (unsigned)gy), dim3(256), 0, stream, (const __bf16*)g, ld, M, C, out, partial, accumulate);
+  else hipLaunchKernelGGL((colsum_kernel<float>), dim3(C, (unsigned)gy), dim3(256), 0, stream, (const float*)g, ld, M, C, out, partial, accumulate);
+  if (gy > 1) hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, (int)gy, C, out, accumulate);
   MIREG_LAUNCH_RET();
 }
 

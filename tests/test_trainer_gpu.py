@@ -401,3 +401,27 @@ def test_batchnorm_num_batches_tracked_follows_torch():
         m.eval()
         m(x)
     assert all(int(v) == 6 for k, v in m.state_dict().items() if k.endswith("num_batches_tracked"))
+
+
+@pytest.mark.parametrize("name,batch", [("pwc", 4), ("flownetc", 4)])
+def test_backward_is_run_to_run_deterministic_with_biased_two_channel_layers(name, batch):
+    """Same weights, same batch, forward + backward eight times: the packed gradient (conv weights, biases, BatchNorm) is bit-identical
+    every time.  PWC / FlowNetC carry biases on their 2-channel heads and upsamplers (PWCNet.py:31-34, submodules.py:32-38); their
+    bias gradients are column sums over up to 256x256xB rows, which used to go through fp32 atomics."""
+    import mireg
+    from mireg.synth import make_pairs
+    torch.manual_seed(3)
+    m = mireg.opticalFlowReg(name, precision="bf16")
+    nets.analytic_weights_(m)
+    tr = mireg.RegistrationTrainer(m.to(DEV), use_graph=False, autotune=False, overlap_optimizer=False)
+    x = make_pairs(batch, 256, seed=2)[0].to(DEV)
+    tr.step(x)
+    torch.cuda.synchronize()
+    ref = None
+    for it in range(8):
+        tr._fwd_bwd()
+        torch.cuda.synchronize()
+        g = tr.flat_g.detach().clone()
+        if ref is None:
+            ref = g
+        assert torch.equal(g, ref), (it, int((g != ref).sum()))
