@@ -1,4 +1,6 @@
-"""Run-to-run bit determinism of the halo kernels (same inputs, many launches, interleaved with other launches)."""
+"""Two identically seeded FlowNetS trainers, four steps: where do they diverge?  Snapshots every engine buffer after step 0 of each
+trainer, lists the differing ones and recomputes the upsampler backward-data outputs on the host (the tool that found the LDS
+write-after-read race and the upsampler backward-data hazard of round 2; MIREG_TINY_MASK=7 re-enables that kernel)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mireg
@@ -48,27 +50,6 @@ for rep in range(2):
     for st in range(4):
         loss = tr.step(xd).clone(); torch.cuda.synchronize()
         rows.append((loss.cpu(), tr.flat_g.detach().cpu().clone() if st == 0 else None, tr.flat_p.detach().cpu().clone()))
-        if engine._DBG_LOG:
-            import torch.nn.functional as F
-            for xb, yb, w, xc0, xC, yc0, nm, addc, acc, ya in engine._DBG_LOG:
-                gup = xb[..., xc0:xc0 + 2].float().permute(0, 3, 1, 2)
-                conv = F.conv2d(gup, w.float(), None, 2, 1).permute(0, 2, 3, 1)
-                base = yb[..., yc0:yc0 + 2].float() if acc else 0.0
-                if addc is not None:
-                    base = base + addc.permute(0, 2, 3, 1)
-                exp = (base + conv).bfloat16().float()
-                nm = f"step {st} {nm}"
-                got = ya[..., yc0:yc0 + 2].float()
-                bad = int(((got - exp).abs() > 0).sum())
-                print(f"trainer {rep} {nm}: kernel output vs its in-stream input clones: {bad} elements off", flush=True)
-                if bad > 8:
-                    nz = torch.nonzero((got - exp).abs() > 0)
-                    print("   positions", nz.tolist())
-                    for q in nz[:12].tolist():
-                        b_, y_, x_, c_ = q
-                        print(f"    {q}: got {got[b_, y_, x_, c_].item():.6f} exp {exp[b_, y_, x_, c_].item():.6f} add {addc[b_, c_, y_, x_].item() if addc is not None else 0:.6f} d_before {yb[b_, y_, x_, yc0 + c_].item():.6f} conv {conv[b_, y_, x_, c_].item():.6f} got-d_before {got[b_, y_, x_, c_].item() - yb[b_, y_, x_, yc0 + c_].item():.6f}")
-                        # which single fine pixel / tap contribution would explain the deviation?
-            engine._DBG_LOG.clear()
         if st == 0:
             e = tr.eng
             snap = {}
