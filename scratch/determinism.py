@@ -33,15 +33,13 @@ for name, cin, cout, k, s, H in [
         if ref is not None:
             print(name, form, "mismatching runs:", bad, "of 29", flush=True)
 # whole trainer: where do two identical trainers diverge?
-from oracle import nets
 from mireg.synth import make_pairs
 x, _ = make_pairs(24, 256, seed=6); xd = x.cuda()
 hist = []
 snaps = []
 for rep in range(2):
     torch.manual_seed(1)
-    mm = mireg.opticalFlowReg("flownets", precision="bf16"); nets.analytic_weights_(mm)
-    tr = mireg.RegistrationTrainer(mm.cuda(), use_graph=os.environ.get('NOGRAPH') != '1', autotune=False,
+    mm = mireg.opticalFlowReg("flownets", precision="bf16");    tr = mireg.RegistrationTrainer(mm.cuda(), use_graph=os.environ.get('NOGRAPH') != '1', autotune=False,
                                    overlap_optimizer=os.environ.get('NOOVL') != '1')
     if os.environ.get('NOSIDE') == '1':
         from mireg import flownets as _fs
@@ -95,7 +93,8 @@ for k in snaps[0]:
 
 # which trainer is wrong, and by what: recompute dflowT[l+1] = bf16(bf16(loss grad) + conv_s2(gup, W_up)) from the snapshots
 import torch.nn.functional as F
-mref = mireg.opticalFlowReg("flownets", precision="bf16"); nets.analytic_weights_(mref)
+torch.manual_seed(1)
+mref = mireg.opticalFlowReg("flownets", precision="bf16")            # same seed as the two trainers: their step-0 weights
 sd = dict(mref.named_parameters())
 upname = {4: "upsampled_flow4_to_3", 5: "upsampled_flow5_to_4", 6: "upsampled_flow6_to_5"}
 for lv in (4, 5, 6):

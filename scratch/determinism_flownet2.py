@@ -2,7 +2,6 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mireg
-from oracle import nets
 from mireg.synth import make_pairs
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 x = make_pairs(4, 256, seed=6)[0].cuda()
@@ -10,7 +9,6 @@ finals = []
 for rep in range(2):
     torch.manual_seed(1)
     reg = mireg.opticalFlowReg("flownet2", precision="bf16")
-    nets.analytic_weights_(reg)
     reg = reg.cuda().train()
     opt = mireg.Adam(reg.parameters(), 1e-4, eps=1e-4)
     for st in range(steps):

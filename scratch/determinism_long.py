@@ -3,7 +3,6 @@ shapes).  python scratch/determinism_long.py [model] [steps] [batch]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mireg
-from oracle import nets
 from mireg.synth import make_pairs
 model = sys.argv[1] if len(sys.argv) > 1 else "flownets"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -17,7 +16,6 @@ finals, losses = [], []
 for rep in range(2):
     torch.manual_seed(1)
     mm = mireg.opticalFlowReg(model, precision="bf16")
-    nets.analytic_weights_(mm)
     tr = mireg.RegistrationTrainer(mm.cuda(), use_graph=True, autotune=False)
     ls = []
     for st in range(steps):

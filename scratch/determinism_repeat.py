@@ -3,7 +3,6 @@ time.  On a mismatch, the layers whose gradient slices differ are listed.  pytho
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mireg
-from oracle import nets
 from mireg.synth import make_pairs
 model = sys.argv[1] if len(sys.argv) > 1 else "pwc"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -14,7 +13,6 @@ if os.environ.get("NOSIDE") == "1":
 x = make_pairs(B, 256, seed=6)[0].cuda()
 torch.manual_seed(1)
 mm = mireg.opticalFlowReg(model, precision="bf16")
-nets.analytic_weights_(mm)
 tr = mireg.RegistrationTrainer(mm.cuda(), use_graph=False, autotune=False, overlap_optimizer=False)
 for _ in range(2):
     tr.step(x)
