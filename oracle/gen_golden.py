@@ -13,7 +13,11 @@ What it does
      oracle's published-definition Correlation is injected in its place, so the
      PWC / FlowNetC fixtures pin everything AROUND the correlation arithmetic
      (convs, warps, concats, scales) but not that arithmetic itself
-     ("parity unpinned" for K7/K8, see oracle/__init__.py).
+     ("parity unpinned" for K7/K8, see oracle/__init__.py).  The same holds for
+     resample2d_package / channelnorm_package in the FlowNet2 fixture (G9): the
+     reference's FlowNet2 / FlowNetSD / FlowNetFusion / FlowNetS classes run with
+     the oracle's Resample2d / ChannelNorm / Correlation in place of the three
+     external layers.
   2. gives reference and oracle models the same analytic weights and inputs,
      asserts the oracle restatement equals the reference (<= 1e-5 abs / rel),
   3. writes inputs-by-formula + expected outputs as small fixtures.
