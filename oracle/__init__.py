@@ -23,5 +23,11 @@ Parity status
     the reference's structural pins (441 / 81 output channels, same HxW,
     1/C normalisation) only.  PWCDCNet.warp is plain torch in the reference
     (PWC/models/PWCNet.py:143-179) and is pinned by running it (G6).
+  * FlowNet2 stack (FlowNetSD, FlowNetFusion, the 6-channel FlowNetS, the
+    FlowNet2 chain): pinned by running the reference's classes (G9) with this
+    package's Correlation / Resample2d / ChannelNorm in place of the three
+    external CUDA layers; Resample2d and ChannelNorm themselves are PARITY
+    UNPINNED (NVIDIA/flownet2-pytorch custom layers, absent and unversioned:
+    published definitions restated).
 """
 from . import ops, nets  # noqa: F401
