@@ -2,6 +2,10 @@
 import os, sys, collections, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mireg
+if os.environ.get('ALT_LIB'):                            # A/B of an alternative build of the library (same process layout)
+    import mireg._lib as _L
+    assert _L._lib is None
+    _L.LIB_PATH = os.environ['ALT_LIB']
 from mireg.engine import PROFILER
 from mireg.synth import make_pairs
 B = int(os.environ.get("B", "24"))
