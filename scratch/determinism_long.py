@@ -3,6 +3,10 @@ shapes).  python scratch/determinism_long.py [model] [steps] [batch]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mireg
+if os.environ.get('ALT_LIB'):                            # A/B of an alternative build of the library
+    import mireg._lib as _L
+    assert _L._lib is None
+    _L.LIB_PATH = os.environ['ALT_LIB']
 from mireg.synth import make_pairs
 model = sys.argv[1] if len(sys.argv) > 1 else "flownets"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
