@@ -4,7 +4,8 @@
 metric  : registration slice-pairs / s, whole job (BASELINE.json), one step = one training step of
           FlowNetS (forward + stn warps + OFEloss + backward + gradient all-reduce + Adam) on a
           batch of synthetic 256x256 pairs, 24 pairs per GPU (weak scaling), bf16 operands.
-usage   : python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+usage   : python bench.py --gpus N --steps K --warmup W      (N > 1 without RANK / WORLD_SIZE in the environment: bench.py
+          starts its own N rank processes through torch.distributed.run before anything touches the GPU)
 output  : ONE JSON line on rank 0 (see DESIGN.md section 7 for every field).
 """
 import argparse
@@ -120,6 +121,25 @@ def model_leg(name, batch, precision, dev, steps=10, warm=4):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes (one per GPU) as children BEFORE this
+    process has made any GPU call, wait for them and leave with their exit code (never re-exec a process that touched the GPU)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,15 +156,43 @@ def main():
     ap.add_argument("--tune-cache", default=None, help="JSON of measured launch shapes (written after tuning, reused when present)")
     ap.add_argument("--no-autotune", action="store_true", help="heuristic launch shapes (counter-collection runs: the tuning pass is slow there)")
     ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch pairs per GPU (the driver's contract); strong: --batch pairs in total, split over the ranks")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 parity-mode train-step leg")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check only: initialise the process group, reduce one number, print the dist block "
+                         "(runs without a GPU over gloo: tests/test_bench_contract.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
+    if args.dry_run:
+        backend = os.environ.get("MIREG_DIST_BACKEND", "nccl" if torch.cuda.device_count() >= world else "gloo")
+        if world > 1:
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+                torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                torch.distributed.init_process_group(backend)
+            t = torch.tensor([float(rank)], device=(torch.device("cuda", local) if backend == "nccl" else "cpu"), dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            assert int(t.item()) == world - 1
+            torch.distributed.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": args.scaling,
+                              "dist": {"world": world, "backend": (torch.distributed.get_backend() if world > 1 else None)}}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    if args.scaling == "strong":
+        assert args.batch % world == 0, "strong scaling: --batch must divide by the number of ranks"
+        args.batch //= world
     local = local % max(torch.cuda.device_count(), 1)            # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -449,6 +497,16 @@ def main():
                 log(f"{nm} batch {bsz}: {others[nm]['pairs_per_s']} pairs/s ({others[nm]['ms_per_step']} ms/step)")
             except Exception as e:                                   # noqa: BLE001
                 others[nm] = {"error": repr(e)}
+        # the mode that meets north_star's "flow L2 < 1e-4": exact-fp32 MFMA operands (parity mode), same FlowNetS step, batch 24
+        if not args.no_fp32_leg and args.precision == "bf16":
+            try:
+                others["flownets_fp32_parity_mode"] = model_leg("flownets", 24, "fp32", dev, steps=5, warm=3)
+                others["flownets_fp32_parity_mode"]["note"] = ("configs[1] in fp32 parity mode (v_mfma_f32_32x32x2_f32 operands; flows match the "
+                                                              "CPU oracle at 1e-4 + 4 x the reference's own fp32 noise, tests/test_bench_parity_gpu.py); "
+                                                              "roofline peak = 157.3 TFLOP/s fp32 matrix")
+                log(f"flownets fp32 batch 24: {others['flownets_fp32_parity_mode']['pairs_per_s']} pairs/s")
+            except Exception as e:                                   # noqa: BLE001
+                others["flownets_fp32_parity_mode"] = {"error": repr(e)}
         # the FlowNet2 stack, registration-wrapper shaped inference
         try:
             import mireg
@@ -502,7 +560,7 @@ def main():
     if rank == 0:
         out = {"metric": f"registration slice-pairs/s ({args.model} train step: fwd + warp + OFEloss + bwd + all-reduce + Adam)",
                "value": round(pairs / dt, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                "config": {"workload": f"{ {'flownets': 'configs[1]', 'flownetc': 'configs[2] shape', 'pwc': 'configs[3] shape'}.get(args.model, 'custom') }: {args.model} {args.size}x{args.size} slice pairs, batch {args.batch}/GPU, "
                                       f"{args.precision} operands fp32 accumulate, train step", "global_batch": args.batch * world,

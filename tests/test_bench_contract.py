@@ -32,3 +32,31 @@ def test_bench_accepts_the_driver_flags():
         assert re.search(r'add_argument\("%s"' % flag, src), flag
     for env in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         assert env in src, env
+
+
+def test_bench_gpus_2_launches_its_own_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no launcher and no RANK / WORLD_SIZE in the environment starts its own two rank processes
+    (torch.distributed.run, 127.0.0.1), they rendezvous, and rank 0 prints ONE JSON line with dist.world == 2.  --dry-run stops
+    after the process-group check, so this runs on the CPU box over gloo; the GPU version of the same path is
+    tests/test_trainer_gpu.py::test_bench_self_launch_two_ranks_one_gpu."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MIREG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dist"] == {"world": 2, "backend": "gloo"} and d["n_gpus"] == 2
+
+
+def test_bench_self_launch_propagates_a_rank_failure():
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MIREG_DIST_BACKEND"] = "no-such-backend"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

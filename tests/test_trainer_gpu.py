@@ -425,3 +425,22 @@ def test_backward_is_run_to_run_deterministic_with_biased_two_channel_layers(nam
         if ref is None:
             ref = g
         assert torch.equal(g, ref), (it, int((g != ref).sum()))
+
+
+def test_bench_self_launch_two_ranks_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it (what a driver that calls it like `--gpus 1` does): bench.py starts its
+    own two rank processes before touching the GPU, both train (gloo rehearsal: two ranks share this card, the exchange is the same
+    bucketed all-reduce RCCL carries on a multi-GPU node), rank 0 prints ONE contract line with dist.world == 2 and a whole-job value."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MIREG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "3", "--batch", "4",
+                        "--size", "64", "--no-3d", "--no-other-models", "--no-cpu-baseline", "--no-autotune"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["dist"] == {"world": 2, "backend": "gloo"} and d["n_gpus"] == 2 and d["config"]["global_batch"] == 8
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"] and d["scaling"] == "weak"
