@@ -247,7 +247,8 @@ typedef struct mireg_conv_desc {
    * N*slab_ld apart */
   long slab_ld;
   /* mireg_conv_gemm / mireg_conv_wgrad kernel choice.  algo 0 = the halo-staged kernel (conv_halo.hip) whenever mireg_conv_halo_eligible says
-   * so, else the ring kernel; 1 = ring kernel; 2 = halo kernel or MIREG_ERR_UNSUPPORTED.  tile_m = pixels per halo tile
+   * so, else the ring kernel; 1 = ring kernel; 2 = halo kernel or MIREG_ERR_UNSUPPORTED; 3 (mireg_conv_gemm only) = the 256-pixel
+   * 8-wave tile of conv_wide.hip (tile_n 128 / 256 columns, 0 = by N) or MIREG_ERR_UNSUPPORTED.  tile_m = pixels per halo tile
    * (0 = by tile count, 128 or 256 forces it). */
   int algo, tile_m;
 } mireg_conv_desc;
@@ -257,6 +258,9 @@ int mireg_conv_halo_eligible(const mireg_conv_desc* desc, long* tiles_out);
 /* 1 when mireg_conv_wgrad takes the halo-staged backward-weights kernel (conv_wgrad_halo.hip) for desc: bf16, square kernel,
  * stride 1 or 2 with every tap-parity class 3x3 / 3x2 / 2x3 / 2x2 (3x3 s1, 5x5 s2, 4x4 s2), dy grid 16 / 32 / 64 wide. */
 int mireg_conv_wgrad_halo_eligible(const mireg_conv_desc* desc);
+/* 1 when algo 3 applies to desc (bf16, 2-D, x_C >= 64); tiles_out (may be NULL) = workgroups per class at the tile width
+ * desc->tile_n selects. */
+int mireg_conv_wide_eligible(const mireg_conv_desc* desc, long* tiles_out);
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream);
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream);
 

@@ -897,6 +897,25 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
 }
 
 template <typename T>
+void launch_reduce(const mireg_conv_desc& p, long M, int ncls, hipStream_t stream) {
+  const long total = M * p.N;
+  long g = (total / 4 + 255) / 256;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)g, ncls), dim3(256), 0, stream, p);
+}
+
+long largest_class_rows(const mireg_conv_desc& p) {
+  const int ncls = p.n_cls > 1 ? p.n_cls : 1;
+  long M = 0;
+  for (int c = 0; c < ncls; ++c) {
+    const long m = (ncls > 1 ? (long)p.n_img * p.cls[c].g_H * p.cls[c].g_W : (long)p.n_img * p.g_H * p.g_W) * (p.g_D > 0 ? p.g_D : 1);
+    M = m > M ? m : M;
+  }
+  return M;
+}
+
+template <typename T>
 int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
   const int ncls = p.n_cls > 1 ? p.n_cls : 1;
   long M = 0;                                                       // largest class decides the grid
@@ -916,13 +935,7 @@ int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
     dim3 grid((unsigned)((M + 127) / 128), ncls, z);
     hipLaunchKernelGGL((conv_gemm_dma_kernel<T, 128, 32, 4, 1>), grid, dim3(256), 0, stream, p);
   }
-  if (z > 1) {
-    const long total = M * p.N;
-    long g = (total / 4 + 255) / 256;
-    if (g > 1024) g = 1024;
-    if (g < 1) g = 1;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)g, ncls), dim3(256), 0, stream, p);
-  }
+  if (z > 1) launch_reduce<T>(p, M, ncls, stream);
   return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
 }
 
@@ -968,11 +981,22 @@ bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
 
 extern "C" int mireg_conv_halo_try(const mireg_conv_desc* p, hipStream_t stream);         // conv_halo.hip
 extern "C" int mireg_conv_wgrad_halo_try(const mireg_conv_desc* p, hipStream_t stream);   // conv_wgrad_halo.hip
+extern "C" int mireg_conv_wide_try(const mireg_conv_desc* p, hipStream_t stream);         // conv_wide.hip
 
 extern "C" {
 
 int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream) {
   if (!desc_ok(desc, false)) return MIREG_ERR_ARG;
+  if (desc->algo == 3) {                                            // 3: the 256-pixel 8-wave tile (conv_wide.hip) or UNSUPPORTED
+    const int rc = mireg_conv_wide_try(desc, stream);
+    if (rc == -100) return MIREG_ERR_UNSUPPORTED;
+    if (rc != MIREG_OK) return rc;
+    if (desc->split_k > 1) {
+      launch_reduce<__bf16>(*desc, largest_class_rows(*desc), desc->n_cls > 1 ? desc->n_cls : 1, stream);
+      return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
+    }
+    return MIREG_OK;
+  }
   if (desc->algo != 1) {                                            // 0: halo-staged kernel when it applies, 2: require it
     const int rc = mireg_conv_halo_try(desc, stream);
     if (rc != -100) return rc;

@@ -248,6 +248,7 @@ USE_TINY = os.environ.get('MIREG_NO_TINY', '0') != '1'   # experiments / A-B run
 # DESIGN.md section 5).  The kernel itself is exact (tests/test_thin_gpu.py).
 TINY_MASK = int(os.environ.get('MIREG_TINY_MASK', '5'))
 USE_HALO = os.environ.get('MIREG_NO_HALO', '0') != '1'   # experiments / A-B runs only
+USE_WIDE = os.environ.get('MIREG_NO_WIDE', '0') != '1'   # experiments / A-B runs only: the 256-pixel 8-wave tile as a tuner candidate
 USE_THIN = True     # module switch (tests compare the thin kernels with the GEMM path)
 
 
@@ -394,7 +395,7 @@ class ConvLayer:
         d.dtype = self.ws.code
 
         def apply(bn: int, split: int, algo: int = 1, tm: int = 0) -> None:
-            d.tile_n = bn if N > 64 else 0
+            d.tile_n = bn if (N > 64 or algo == 3) else 0
             d.split_k, d.algo, d.tile_m = split, algo, tm
             d.slab = None
             if split > 1:
@@ -402,13 +403,17 @@ class ConvLayer:
                 self.ws.need_scratch(ncls * split * M * N)
                 d.slab = self.ws.get_scratch().data_ptr()
 
-        def tiles_for(bn: int) -> int:
-            return ((M + 127) // 128) * ((N + bn - 1) // bn) * ncls
+        def tiles_for(bn: int, bm: int = 128) -> int:
+            return ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * ncls
         bn = 128 if N > 64 else (64 if N > 32 else 32)
         if FORCE_TILE_N and N > 64:
             bn = FORCE_TILE_N
         key = (self.name, site, M, N, K, ncls)
         if FORCE_ALGO is not None:                          # tests / A-B runs: (algo, tile_m[, tile_n]); raises if not applicable
+            if FORCE_ALGO[0] == 3:                          # (3, 256, tile_n[, split]): the 256-pixel 8-wave tile of conv_wide.hip
+                apply(FORCE_ALGO[2] if len(FORCE_ALGO) > 2 else (256 if N > 128 else 128),
+                      FORCE_ALGO[3] if (len(FORCE_ALGO) > 3 and allow_split) else 1, 3, 256)
+                return
             apply(FORCE_ALGO[2] if len(FORCE_ALGO) > 2 else bn, 1 if FORCE_ALGO[0] == 2 else (_split_for(tiles_for(bn), nk) if allow_split else 1),
                   FORCE_ALGO[0], FORCE_ALGO[1])
             return
@@ -439,6 +444,14 @@ class ConvLayer:
                 for i, tm in enumerate((128, 256)):
                     if htiles[i]:
                         cands.add((b, 1, 2, tm))
+        # the 256-pixel 8-wave tile (conv_wide.hip): 256 or 128 columns, split-K where the grid would leave CUs idle
+        if USE_WIDE and self.ws.code == DT_BF16 and bool(_lib.lib().mireg_conv_wide_eligible(ctypes.byref(d), None)):
+            nk64 = (K + 63) // 64
+            for b in ((256, 128) if N > 128 else (128,)):
+                t = tiles_for(b, 256)
+                for sp in (1, 2, 3, 4, 6, 8):
+                    if sp <= max(nk64 // 4, 1) and 64 <= t * sp <= 1536 and ncls * sp * M * N <= (1 << 26):
+                        cands.add((b, sp, 3, 256))
         best, best_t = heur, float("inf")
         st = _stream()
         for c in sorted(cands):
@@ -515,6 +528,8 @@ class ConvLayer:
         bn = tile_n or (128 if N > 64 else (64 if N > 32 else 32))
         if algo == 2:
             return f"conv_halo_kernel<{tile_m},{bn}>"
+        if algo == 3:
+            return f"conv_wide_kernel<256,{bn}>" + ("+splitk" if split > 1 else "")
         return f"conv_gemm_kernel<128,{bn}>" + ("+splitk" if split > 1 else "")
 
     @staticmethod
