@@ -97,7 +97,7 @@ def zero_many_table(bufs: Sequence[torch.Tensor], device):
 
 def zero_tensors(bufs: Sequence[torch.Tensor]) -> None:
     """Zero whole tensors with ONE mireg_zero_many launch (the tables are cached per set of buffers): the step's only fills."""
-    key = tuple((b.data_ptr(), b.numel() * b.element_size()) for b in bufs)   # (address, bytes): an address can be re-used
+    key = (bufs[0].device.index,) + tuple((b.data_ptr(), b.numel() * b.element_size()) for b in bufs)   # device, (address, bytes)
     tab = _ZERO_TABLES.get(key)
     if tab is None:
         tab = _ZERO_TABLES[key] = zero_many_table(bufs, bufs[0].device)
@@ -241,12 +241,10 @@ WGRAD_ALGO = int(os.environ.get('MIREG_WGRAD_ALGO', '0'))         # tests / A-B 
 FORCE_ALGO = None      # tests only: (algo, tile_m[, tile_n]) for every mireg_conv_gemm launch
 THIN_GEMM_ROWS = int(os.environ.get('MIREG_THIN_GEMM_ROWS', '1024'))   # heads with at least this many pixels run as 1x1 GEMMs
 USE_TINY = os.environ.get('MIREG_NO_TINY', '0') != '1'   # experiments / A-B runs only
-# which forms of the 2->2 upsamplers take the pixel-parallel kernels: 1 forward, 2 backward-data, 4 backward-weights.
-# Backward-data stays on the GEMM path by default: launched back to back behind its producer while the wgrad stream is
-# writing slabs, the 3-us kernel was measured to read operands that the preceding main-stream kernel had not made
-# visible yet (run-to-run differences of two identically seeded trainers; a delay in front of it removes them, see
-# DESIGN.md section 5).  The kernel itself is exact (tests/test_thin_gpu.py).
-TINY_MASK = int(os.environ.get('MIREG_TINY_MASK', '5'))
+# which forms of the 2->2 upsamplers take the pixel-parallel kernels: 1 forward, 2 backward-data, 4 backward-weights.  Round 2 kept
+# backward-data off (mask 5) because two identically seeded trainers diverged with it; round 3 traced that to packed-fp32 VALU
+# code in the kernel (csrc/Makefile): fixed at the compiler flag, all three forms are on.
+TINY_MASK = int(os.environ.get('MIREG_TINY_MASK', '7'))
 USE_HALO = os.environ.get('MIREG_NO_HALO', '0') != '1'   # experiments / A-B runs only
 USE_WIDE = os.environ.get('MIREG_NO_WIDE', '0') != '1'   # experiments / A-B runs only: the 256-pixel 8-wave tile as a tuner candidate
 USE_THIN = True     # module switch (tests compare the thin kernels with the GEMM path)
@@ -609,9 +607,14 @@ class ConvLayer:
             self.wgrad_split = _lib.lib().mireg_thin_conv_wgrad_tiles(dy.B, dy.H, dy.W, self.Cip, self.ws.code, None)
         elif self.stem:
             self.wgrad_split = _lib.lib().mireg_stem_conv_blocks(x.B, x.H, x.W)
-        elif self.name in self.ws.tuned_wgrad:
-            tw = self.ws.tuned_wgrad[self.name]
+        elif self._wgrad_key(x, dy) in self.ws.tuned_wgrad:
+            tw = self.ws.tuned_wgrad[self._wgrad_key(x, dy)]
             self.wgrad_split, self.wgrad_algo = (tw, 0) if isinstance(tw, int) else (tw[0], tw[1])
+            if self.wgrad_algo == 2:                          # a cached "halo kernel" choice must still apply to these operands
+                probe = self._wgrad_desc(x, dy, 1, 0, 0)
+                if not _lib.lib().mireg_conv_wgrad_halo_eligible(ctypes.byref(probe)):
+                    self.wgrad_algo = 0
+            self.wgrad_split = max(1, min(self.wgrad_split, max(nk // 8, 1)))
             self._wgrad_tuned = True
         else:
             self.wgrad_split = 1 if tiles >= NUM_CU else max(1, min((3 * NUM_CU) // tiles, max(nk // 8, 1), 192))   # <= 768 resident WGs
@@ -623,6 +626,10 @@ class ConvLayer:
             self.grad_w = torch.zeros_like(self.weight, dtype=F32)
         if self.bias is not None and self.grad_b is None:
             self.grad_b = torch.zeros_like(self.bias, dtype=F32)
+
+    def _wgrad_key(self, x: View, dy: View) -> str:
+        """Cache key of a measured backward-weights launch shape: the layer AND the operands it was measured on."""
+        return f"{self.name}|{dy.B}x{dy.H}x{dy.W}|{x.H}x{x.W}|{self.ws.code}"
 
     def _wgrad_desc(self, x: View, dy: View, split: int, slab_ptr: int, algo: Optional[int] = None) -> ConvDesc:
         d = ConvDesc()
@@ -681,7 +688,7 @@ class ConvLayer:
             if c < best_c:
                 best, best_c = (sp, algo), c
         self._wgrad_tuned = True
-        self.ws.tuned_wgrad[self.name] = list(best)
+        self.ws.tuned_wgrad[self._wgrad_key(x, dy)] = list(best)
         self.wgrad_algo = best[1]
         if best[0] != self.wgrad_split:
             self.wgrad_split = best[0]

@@ -21,7 +21,7 @@ import torch.nn as nn
 from .engine import F32, BatchNormAct, lrelu_bwd, nchw_to_view, zero_tensors
 from .flownet2_ops import ChannelNorm, Resample2d, Upsample
 from .flownetc import FlowNetC
-from .flownets import (DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, FlowNetSEngine, PredictorEngineBase, conv_block,
+from .flownets import (drop_engines, DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, FlowNetSEngine, PredictorEngineBase, conv_block,
                        count_bn_batches, install_bn_counter_hook)
 
 # (name, cin, cout, stride), all 3x3 -- flownet2/networks/FlowNetSD.py:17-29
@@ -363,7 +363,7 @@ class _EngineCache:
             raise RuntimeError("model and input are on different devices")
         key = (tuple(x.shape), x.device, dtype, p0.data_ptr())
         if key not in self._engines:
-            self._engines.clear()
+            drop_engines(self)
             B, C, H, W = x.shape
             if C != channels:
                 raise RuntimeError(f"{type(self).__name__} expects (B,{channels},H,W), got {tuple(x.shape)}")

@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib
 from .correlation import correlation_bwd_views, Correlation, correlation_views
 from .engine import BatchNormAct, F32, _stream, lrelu_bwd, nchw_to_view
-from .flownets import (DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block, count_bn_batches,
+from .flownets import (drop_engines, DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block, count_bn_batches,
                        install_bn_counter_hook)
 
 
@@ -235,7 +235,7 @@ class FlowNetC(nn.Module):
         dtype = torch.bfloat16 if self.precision == "bf16" else torch.float32
         key = (tuple(x.shape), x.device, dtype, next(self.parameters()).data_ptr())
         if key not in self._engines:
-            self._engines.clear()
+            drop_engines(self)
             B, C, H, W = x.shape
             if C != 2:
                 raise RuntimeError(f"FlowNetC expects (B,2,H,W) [fixed, moving], got {tuple(x.shape)}")

@@ -6,12 +6,15 @@ kernel sequences over persistent NHWC buffers (no torch.cat, no ATen/MIOpen call
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 
 from . import _lib
+from . import engine as engine_mod
 from .engine import (DT_BF16, F32, BatchNormAct, ConvLayer, View, Workspace, _stream, assign_tiles, cast_from_f32, zero_tensors,
                      lrelu_bwd, nchw_to_view, upload_table)
 
@@ -37,6 +40,18 @@ def count_bn_batches(eng) -> None:
     call; siamese streams wrap one module twice and so count twice, as in the reference)."""
     for b in eng.bns.values():
         b.pending += 1
+
+
+def drop_engines(module: nn.Module) -> None:
+    """Forget the cached engines of a predictor (shape / device / dtype change) WITHOUT losing the training forwards their
+    BatchNorms have counted: num_batches_tracked goes into every checkpoint (train.py:183-201)."""
+    for eng in getattr(module, "_engines", {}).values():
+        for b in getattr(eng, "bns", {}).values():
+            if b.pending:
+                b.bn.num_batches_tracked += b.pending
+                b.pending = 0
+    module._engines.clear()
+    engine_mod._ZERO_TABLES.clear()                          # device tables keyed by the dropped engines' buffer addresses
 
 
 def install_bn_counter_hook(module: nn.Module) -> None:
@@ -88,8 +103,10 @@ class PredictorEngineBase:
         ev.record(torch.cuda.current_stream())
         return ev
 
+    _MAIN_ONLY = tuple(t for t in os.environ.get("MIREG_WGRAD_ON_MAIN", "").split(",") if t)   # experiments: layer-name prefixes kept off the side stream
+
     def wgrad_async(self, lay: ConvLayer, x: View, dy: View, slot: int = 0, after=None) -> None:
-        if not self.use_side_stream:
+        if not self.use_side_stream or (self._MAIN_ONLY and lay.name.startswith(self._MAIN_ONLY)):
             lay.run_wgrad(x, dy, slot)
             return
         if getattr(self, "_side", None) is None:
@@ -336,7 +353,8 @@ class FlowNetDecoderMixin:
             gup = dc[lvl].slice(cs + cd, 2)
             up = L[f"up{lvl + 1}"]
             gt = glvl.get(lvl + 1)
-            fused = up.tiny_bwd_data_ok(gup, self.dflowT[lvl + 1]) and gt is not None and gt.dtype == torch.float32
+            fused = (up.tiny_bwd_data_ok(gup, self.dflowT[lvl + 1]) and gt is not None and gt.dtype == torch.float32
+                     and os.environ.get("MIREG_TINY_NOFUSE", "0") != "1")
             if not fused:
                 load_loss_grad(lvl + 1)                                       # dflowT[lvl+1] <- loss grad
             m_up = self.mark()
@@ -571,7 +589,7 @@ class FlowNetS(nn.Module):
             raise RuntimeError("model and input are on different devices")
         key = (tuple(x.shape), x.device, dtype, p0.data_ptr())
         if key not in self._engines:
-            self._engines.clear()
+            drop_engines(self)
             B, C, H, W = x.shape
             if C != 2:
                 raise RuntimeError(f"FlowNetS expects (B,2,H,W) [fixed, moving], got {tuple(x.shape)}")

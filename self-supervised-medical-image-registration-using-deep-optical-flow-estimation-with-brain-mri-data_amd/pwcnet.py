@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import _lib
 from .correlation import Correlation, WarpBwdWorkspace, correlation_bwd_views, correlation_views, pwc_warp_bwd_views, pwc_warp_views
 from .engine import F32, View, _stream, cast_from_f32, lrelu_bwd, nchw_to_view, zero_many_table, zero_tensors
-from .flownets import PredictorEngineBase
+from .flownets import drop_engines, PredictorEngineBase
 
 SLOPE = 0.1
 PYRAMID = [(1, 16), (16, 32), (32, 64), (64, 96), (96, 128), (128, 196)]      # PWCNet.py:50-67
@@ -333,7 +333,7 @@ class PWCDCNet(nn.Module):
         dtype = torch.bfloat16 if self.precision == "bf16" else torch.float32
         key = (tuple(x.shape), x.device, dtype, next(self.parameters()).data_ptr())
         if key not in self._engines:
-            self._engines.clear()
+            drop_engines(self)
             B, C, H, W = x.shape
             if C != 2:
                 raise RuntimeError(f"PWCDCNet expects (B,2,H,W) [fixed, moving], got {tuple(x.shape)}")

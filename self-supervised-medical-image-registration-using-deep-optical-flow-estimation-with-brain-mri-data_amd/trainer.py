@@ -149,6 +149,9 @@ class RegistrationTrainer:
                  autotune: bool = True, tune_cache: Optional[str] = None, overlap_optimizer: bool = True):
         self.model = model
         self.predictor = model.predictor
+        if not hasattr(self.predictor, "engine_for"):
+            raise RuntimeError(f"RegistrationTrainer: predictor {type(self.predictor).__name__} has no fused engine "
+                               "(engine_for); train it through autograd: loss.backward() + mireg.Adam")
         self.lr, self.betas, self.eps = lr, betas, eps
         self.loss_hyper = (lamb_da, gamma, zeta)
         self.use_graph = use_graph

@@ -2,7 +2,8 @@
 
 configs[1]  FlowNetS, 24 pairs of 256x256: one RegistrationTrainer.step, autotuned launch shapes + hipGraph replay, bf16
             (the benchmarked configuration) and fp32 (parity mode): losses and all six flows of the first steps.
-configs[2]  FlowNetC, 24 pairs;  configs[3]  PWC-DC-Net, 48 pairs: eval-mode forward, fp32 and bf16.
+configs[2]  FlowNetC, 24 pairs;  configs[3]  PWC-DC-Net, 48 pairs: eval-mode forward (fp32 and bf16) and, since round 3, the training
+            step with autotune + hipGraph in fp32: loss scalars of three steps and first-step weight gradients vs the oracle.
 configs[4]  FlowNetS-3D at FULL width on a 128^3 volume pair: training-mode forward, OFEloss3d, a handful of parameter gradients.
 
 Tolerances.  fp32 (exact-fp32 MFMA): |flow error| <= 1e-4 * max(1, scale) + 4 * noise, noise = the oracle's own fp32 distance
@@ -121,6 +122,76 @@ def test_flownetc_batch24_and_pwc_batch48_eval_forward_vs_oracle(name, B):
         torch.cuda.empty_cache()
 
 
+def _packed_grad_of(eng, flat_g, lay):
+    o = eng.flat_off[id(lay.weight)]
+    return flat_g[o:o + lay.Co * lay.Kf].view(lay.Co, lay.kh * lay.kw, lay.Cip)[..., :lay.Ci].double().cpu()
+
+
+@pytest.mark.parametrize("name,B", [("flownetc", 24), ("pwc", 48)])
+def test_flownetc_batch24_and_pwc_batch48_train_step_graph_autotune_vs_oracle(name, B):
+    """BASELINE configs[2] / [3] as bench.py runs them: RegistrationTrainer.step with autotuned launch shapes (768-way pixel splits, the
+    vector-ALU cost-volume backward at B=48, the 256-pixel tiles) and hipGraph replay, fp32 parity mode, against the CPU oracle's
+    training steps: the four loss scalars of three steps and, at the first step, the weight gradients of layers spread over the
+    network (packed-domain gradient of the fused trainer vs torch autograd through the oracle), bounded by the oracle's own fp32
+    noise measured against its float64 run (G1's form: rel L2 <= 5e-3 + 8 * noise; cosine >= 0.999)."""
+    import copy
+    import mireg
+    from mireg.synth import make_pairs
+    torch.manual_seed(1)
+    model = mireg.opticalFlowReg(name, precision="fp32")
+    nets.analytic_weights_(model)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x, _ = make_pairs(B, 256, seed=6)
+    om = nets.OpticalFlowReg(name)
+    om.load_state_dict(sd)
+    om.train()
+    opt = torch.optim.Adam(om.parameters(), 1e-4, betas=(0.9, 0.999), eps=1e-4)
+    ref_losses, g32 = [], None
+    for st in range(3):
+        flows, warped, _, _ = om(x)
+        vals = oops.ofe_loss(flows, warped, x[:, 0:1])
+        opt.zero_grad(); vals[3].backward()
+        if st == 0:
+            g32 = {k: p.grad.detach().double().clone() for k, p in om.named_parameters()}
+        opt.step()
+        ref_losses.append([float(v) for v in vals])
+    o64 = nets.OpticalFlowReg(name)
+    o64.load_state_dict(sd)
+    o64 = o64.double().train()
+    f64, w64, _, _ = o64(x.double())
+    oops.ofe_loss(f64, w64, x[:, 0:1].double())[3].backward()
+    g64 = {k: p.grad.detach().clone() for k, p in o64.named_parameters()}
+
+    tr = mireg.RegistrationTrainer(model.to(DEV), use_graph=True, autotune=True)
+    xd = x.to(DEV)
+    got_losses = [tr.step(xd).tolist()]
+    torch.cuda.synchronize()
+    eng = tr.eng
+    pname = {id(p): k for k, p in model.named_parameters()}
+    lays = [l for l in eng.layers.values() if l.wgrad_slab is not None and l.Co * l.Kf >= 4096]
+    picks = [lays[i] for i in sorted({0, 1, len(lays) // 4, len(lays) // 2, (3 * len(lays)) // 4, len(lays) - 2, len(lays) - 1})]
+    report = {}
+    for lay in picks:
+        k = pname[id(lay.weight)]
+        a = _packed_grad_of(eng, tr.flat_g, lay)                                        # [Co][taps][Ci]
+        b64 = g64[k].reshape(lay.Co, lay.Ci, lay.kh * lay.kw).permute(0, 2, 1)
+        b32 = g32[k].reshape(lay.Co, lay.Ci, lay.kh * lay.kw).permute(0, 2, 1)
+        noise = ((b32 - b64).norm() / b64.norm()).item()
+        rel = ((a - b64).norm() / b64.norm()).item()
+        cos = (torch.dot(a.flatten(), b64.flatten()) / (a.norm() * b64.norm())).item()
+        report[k] = (rel, noise, cos)
+        assert rel <= 5e-3 + 8 * noise and cos >= 0.999, (k, rel, noise, cos)
+    print(name, "gradient (rel L2 vs fp64 oracle, oracle-fp32 noise, cosine):", report)
+    for _ in range(2):                                       # step 2 eager, step 3 captures the graphs and replays them
+        got_losses.append(tr.step(xd).tolist())
+    assert tr._graphs is not None and len(tr.eng.ws.tuned) > 10
+    for a, b in zip(got_losses[0], ref_losses[0]):
+        assert abs(a - b) <= 5e-5 * abs(b) + 1e-7, (got_losses[0], ref_losses[0])
+    for k, tol in ((1, 5e-3), (2, 2e-2)):                    # later steps: Adam's +-lr moves of noise-level gradients (see the FlowNetS test above)
+        for a, b in zip(got_losses[k], ref_losses[k]):
+            assert abs(a - b) <= tol * abs(b) + 1e-6, (k, got_losses[k], ref_losses[k])
+
+
 def test_flownets3d_full_width_128cubed_vs_oracle():
     """BASELINE configs[4] at its real width (64..1024 channels) on one 128^3 pair, fp32: training-mode forward (batch statistics),
     OFEloss3d and parameter gradients at the top, the middle and the bottom of the network against torch autograd on the CPU."""
@@ -147,14 +218,27 @@ def test_flownets3d_full_width_128cubed_vs_oracle():
         assert err <= 2e-3 * max(1.0, scale), (i, err, scale)       # BatchNorm3d over one sample's voxels, 10 layers deep
     for a, b in zip(vals, vals_ref):
         assert abs(a.item() - b.item()) <= 2e-3 * abs(b.item()) + 1e-6
+    # parameter gradients against the oracle's own float64 run, bounded by the oracle's measured fp32 noise (as fixture G1 does for
+    # FlowNetS): rel L2 <= 5e-3 + 8 * noise_k, noise_k = |oracle fp32 - oracle fp64| / |oracle fp64| for that parameter.  The deepest
+    # layers see 2^3 .. 4^3 voxels of ONE sample behind BatchNorm3d, so their fp32 noise is orders above the shallow layers'.
+    import copy
+    o64 = nets.OpticalFlowReg3d(1)
+    o64.load_state_dict(sd)
+    o64 = o64.double().train()
+    f64, w64 = o64(x.double())
+    oops.ofe_loss_3d(f64, w64, x[:, 0:1].double())[3].backward()
+    ref64 = {k: p.grad.detach().clone() for k, p in o64.named_parameters()}
     P = dict(m.named_parameters())
     names = [k for k in ref if k.endswith("weight") and ref[k].dim() == 5]
     picks = [names[0], names[len(names) // 3], names[len(names) // 2], names[-4], names[-1]]
+    report = {}
     for k in picks:
-        a, b = P[k].grad.double().flatten().cpu(), ref[k].double().flatten()
-        cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)).item()
-        assert cos > 0.99, (k, cos)              # the deepest layers see 2^3 .. 4^3 voxels of one sample behind BatchNorm3d
-        assert abs(a.norm().item() / b.norm().item() - 1.0) < 5e-2, (k, a.norm().item(), b.norm().item())
+        a, b32, b64 = P[k].grad.double().flatten().cpu(), ref[k].double().flatten(), ref64[k].flatten()
+        noise = ((b32 - b64).norm() / b64.norm()).item()
+        rel = ((a - b64).norm() / b64.norm()).item()
+        report[k] = (rel, noise)
+        assert rel <= 5e-3 + 8 * noise, (k, rel, noise)
+    print("FlowNetS-3D gradient rel L2 vs fp64 oracle (HIP, oracle-fp32 noise):", report)
 
 
 def test_model_forward_with_segs_is_the_reference_4_tuple():

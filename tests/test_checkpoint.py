@@ -93,3 +93,30 @@ def test_pretrained_loader_accepts_bare_and_prefixed_checkpoints(tmp_path):
     torch.save({"something.else": torch.zeros(3)}, junk)
     with pytest.raises(RuntimeError, match="no tensor of the checkpoint matches"):
         mireg.opticalFlowReg("flownets", pretrained=junk)
+
+
+def test_fused_trainer_refuses_a_predictor_without_an_engine():
+    """opticalFlowReg('flownet2') is constructible, but the fused RegistrationTrainer only drives predictors with a buffer engine;
+    it must say so at construction (before any flat optimizer buffer exists), not die in the first step."""
+    import pytest
+    import torch
+    import mireg
+
+    class NoEngine(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.predictor = torch.nn.Conv2d(2, 2, 3)
+    with pytest.raises(RuntimeError, match="no fused engine"):
+        mireg.RegistrationTrainer(NoEngine())
+
+
+def test_measured_wgrad_shapes_are_cached_per_operand_shape():
+    """A backward-weights launch shape measured at one batch / image size must not be replayed on another (the short last batch of
+    an epoch, another resolution): the cache key carries the operand shapes and the dtype."""
+    import torch
+    from mireg.engine import ConvLayer, View, Workspace
+    ws = Workspace(torch.device("cpu"), torch.bfloat16)
+    lay = ConvLayer("conv3_1", torch.zeros(256, 256, 3, 3), None, 1, 1, 1, ws)
+    mk = lambda B, H: View(torch.zeros(1, 1, 1, 256, dtype=torch.bfloat16), B, H, H, 256)
+    k24, k7, k64 = lay._wgrad_key(mk(24, 32), mk(24, 32)), lay._wgrad_key(mk(7, 32), mk(7, 32)), lay._wgrad_key(mk(24, 64), mk(24, 64))
+    assert len({k24, k7, k64}) == 3 and k24.startswith("conv3_1|")

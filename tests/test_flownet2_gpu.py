@@ -94,6 +94,94 @@ def test_registration_wrapper_with_flownet2():
     assert moved > 0.9 * len(before) and torch.isfinite(loss)
 
 
+def _grad_report(m_hip, m_cpu, m_ref):
+    """Against m_ref (the oracle run in float64): relative L2 over all parameter gradients together and the worst per-parameter
+    relative L2 among the gradients that carry at least 1e-3 of the total norm, for the HIP model and for the fp32 oracle itself
+    (= the fp32 noise of this computation: LeakyReLU kink flips, few-sample BatchNorms)."""
+    gr = {k: p.grad.detach().double().flatten() for k, p in m_ref.named_parameters()}
+    out = []
+    for mod in (m_hip, m_cpu):
+        g = {k: p.grad.detach().double().cpu().flatten() for k, p in mod.named_parameters()}
+        assert set(g) == set(gr)
+        tot = torch.cat([gr[k] for k in gr]).norm().item()
+        err = torch.cat([g[k] - gr[k] for k in gr]).norm().item()
+        worst = max(((g[k] - gr[k]).norm() / gr[k].norm()).item() for k in gr if gr[k].norm().item() > 1e-3 * tot)
+        out.append((err / tot, worst))
+    return out
+
+
+@pytest.mark.parametrize("which", ["FlowNetSD", "FlowNetFusion", "FlowNet2S"])
+def test_flownet2_subnetworks_fp32_golden(golden, which):
+    import mireg
+    g = golden("g9_flownet2")
+    key, shape, seed, ocls = {"FlowNetSD": ("flownetsd", (2, 2, 64, 64), 21, nets.FlowNetSD),
+                              "FlowNetFusion": ("flownetfusion", (2, 9, 64, 64), 22, nets.FlowNetFusion),
+                              "FlowNet2S": ("flownets", (2, 6, 64, 64), 23, nets.FlowNet2S)}[which]
+    m = getattr(mireg, which)(None, batchNorm=True, precision="fp32")
+    assert list(m.state_dict().keys()) == list(ocls(None, batchNorm=True).state_dict().keys())
+    nets.analytic_weights_(m)
+    m = m.to(DEV)
+    x = nets.analytic_input(shape, seed=seed, lo=-1.0, hi=1.0).to(DEV)
+    for mode in ("train", "eval"):
+        m.train(mode == "train")
+        with torch.no_grad():
+            out = m(x)
+        out = out if isinstance(out, tuple) else (out,)
+        assert len(out) == sum(k.startswith(f"{key}_{mode}_") for k in g.files)
+        # train mode: the deep BatchNorms normalise over 2..32 samples here (64x64 inputs, batch 2), which amplifies fp32
+        # summation-order noise exactly as G1 records for FlowNetS (DESIGN.md section 2)
+        tol = 3e-3 if mode == "train" else 5e-4
+        for i, o in enumerate(out):
+            assert _err(o, g[f"{key}_{mode}_{i}"]) <= tol, (mode, i, _err(o, g[f"{key}_{mode}_{i}"]))
+
+
+def test_flownet2_chain_fp32_golden_and_bf16(golden):
+    import mireg
+    g = golden("g9_flownet2")
+    m = mireg.FlowNet2(None, batchNorm=True, precision="fp32")
+    assert list(m.state_dict().keys()) == list(nets.FlowNet2(None, batchNorm=True).state_dict().keys())
+    nets.analytic_weights_(m)
+    m = m.to(DEV).eval()
+    x = nets.analytic_input((1, 2, 256, 256), seed=24).to(DEV)
+    with torch.no_grad():
+        st = m.stages(x)
+        a, b = m(x)
+    assert a.shape == (1, 2, 256, 256) and torch.equal(a, b)              # flownet2/models.py:189 returns the fused flow twice
+    for name, t in zip(("flownetc_flow2", "flownets1_flow2", "flownets2_flow2", "flownetsd_flow2"), st[:4]):
+        assert _err(t, g[f"flownet2_{name}"]) <= 1e-3, (name, _err(t, g[f"flownet2_{name}"]))
+    assert _err(st[-1][:, :, ::2, ::2], g["flownet2_fused"]) <= 2e-3, _err(st[-1][:, :, ::2, ::2], g["flownet2_fused"])
+    m16 = mireg.FlowNet2(None, batchNorm=True, precision="bf16")
+    m16.load_state_dict(m.state_dict())
+    m16 = m16.to(DEV).eval()
+    with torch.no_grad():
+        f16 = m16(x)[0]
+    rel = ((f16 - a).norm() / a.norm()).item()
+    assert rel < 0.2, rel                                  # measured 0.12 with these random weights
+
+
+def test_registration_wrapper_with_flownet2():
+    """opticalFlowReg('flownet2') (reference models.py:212-225): two identical full-resolution flows, each warped."""
+    import mireg
+    reg = mireg.opticalFlowReg("flownet2", precision="bf16").to(DEV).eval()
+    x = nets.analytic_input((2, 2, 256, 256), seed=5).to(DEV)
+    with torch.no_grad():
+        flows, warped, _, _ = reg(x)
+    assert len(flows) == 2 and len(warped) == 2 and flows[0].shape == (2, 2, 256, 256) and warped[0].shape == (2, 1, 256, 256)
+    assert torch.isfinite(flows[0]).all() and torch.isfinite(warped[0]).all()
+    # the reference's training loop on it (train.py:48-57): forward, OFEloss, backward, Adam(eps=1e-4)
+    reg.train()
+    opt = mireg.Adam(reg.parameters(), 1e-4, eps=1e-4)
+    before = [p.detach().clone() for p in reg.parameters()]
+    flows, warped, _, _ = reg(x)
+    loss = mireg.OFEloss(flows, warped, x[:, 0:1])[3]
+    opt.zero_grad()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in reg.parameters())
+    opt.step()
+    moved = sum(int(not torch.equal(a, b)) for a, b in zip(before, reg.parameters()))
+    assert moved > 0.9 * len(before) and torch.isfinite(loss)
+
+
 def _grad_report(m_hip, m_cpu):
     """(relative L2 over all parameter gradients together, worst per-parameter relative L2 among the gradients that carry
     at least 1e-3 of the total norm)."""
@@ -130,11 +218,21 @@ def test_flownet2_subnetworks_backward_vs_cpu_autograd(which):
     cots = [torch.randn(t.shape, generator=gen) for t in oc]
     sum((a * c).sum() for a, c in zip(oc, cots)).backward()
     sum((a * c.to(DEV)).sum() for a, c in zip(og, cots)).backward()
-    total, worst = _grad_report(m, o)
-    assert total < 1e-2 and worst < 3e-2, (total, worst)
+    # the same computation in float64 is the reference; the fp32 oracle's distance from it is the noise unit of the bound (G1's form)
+    import copy
+    o64 = copy.deepcopy(o).double()
+    o64.zero_grad()
+    x64 = x.double().clone().requires_grad_(need_dx)
+    o64o = o64(x64)
+    o64o = o64o if isinstance(o64o, tuple) else (o64o,)
+    sum((a * c.double()).sum() for a, c in zip(o64o, cots)).backward()
+    (total, worst), (n_total, n_worst) = _grad_report(m, o, o64)
+    assert total <= 5e-3 + 8 * n_total and worst <= 5e-3 + 8 * n_worst, (which, total, worst, n_total, n_worst)
+    print(which, "gradient rel L2 vs fp64 oracle: HIP", (total, worst), "fp32 oracle", (n_total, n_worst))
     if need_dx:
-        rel = ((xg.grad.cpu() - xc.grad).norm() / xc.grad.norm()).item()
-        assert rel < 1e-2, rel
+        rel = ((xg.grad.cpu().double() - x64.grad).norm() / x64.grad.norm()).item()
+        noise = ((xc.grad.double() - x64.grad).norm() / x64.grad.norm()).item()
+        assert rel <= 5e-3 + 8 * noise, (rel, noise)
 
 
 def test_flownet2_trains_end_to_end():
@@ -152,9 +250,18 @@ def test_flownet2_trains_end_to_end():
     cot = torch.randn(2, 2, 256, 256, generator=torch.Generator().manual_seed(42))
     (o(x)[0] * cot).sum().backward()
     (m(x.to(DEV))[0] * cot.to(DEV)).sum().backward()
+    # float64 run of the oracle = reference; per sub-network: rel L2 <= 5e-3 + 8 * (the fp32 oracle's own distance from it)
+    import copy
+    o64 = copy.deepcopy(o).double()
+    o64.zero_grad()
+    (o64(x.double())[0] * cot.double()).sum().backward()
+    report = {}
     for sub in ("flownetc", "flownets_1", "flownets_2", "flownets_d", "flownetfusion"):
         gh = torch.cat([p.grad.detach().double().cpu().flatten() for p in getattr(m, sub).parameters()])
         gc = torch.cat([p.grad.detach().double().flatten() for p in getattr(o, sub).parameters()])
-        assert gc.norm().item() > 0
-        cos = torch.nn.functional.cosine_similarity(gh, gc, dim=0).item()
-        assert cos > 0.99, (sub, cos)
+        gr = torch.cat([p.grad.detach().flatten() for p in getattr(o64, sub).parameters()])
+        assert gr.norm().item() > 0
+        rel, noise = ((gh - gr).norm() / gr.norm()).item(), ((gc - gr).norm() / gr.norm()).item()
+        report[sub] = (rel, noise)
+        assert rel <= 5e-3 + 8 * noise, (sub, rel, noise)
+    print("FlowNet2 end-to-end gradient rel L2 vs fp64 oracle per sub-network (HIP, oracle-fp32 noise):", report)

@@ -444,3 +444,21 @@ def test_bench_self_launch_two_ranks_one_gpu():
     d = json.loads(lines[0])
     assert d["dist"] == {"world": 2, "backend": "gloo"} and d["n_gpus"] == 2 and d["config"]["global_batch"] == 8
     assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"] and d["scaling"] == "weak"
+
+
+def test_batchnorm_counter_survives_a_batch_size_change():
+    """The engine is rebuilt when the batch shape changes (the short last batch of an epoch); the training forwards its BatchNorms
+    had counted must reach num_batches_tracked all the same (train.py:183-201 checkpoints it)."""
+    import mireg
+    from mireg.synth import make_pairs
+    torch.manual_seed(0)
+    m = mireg.opticalFlowReg("flownets", precision="bf16").to(DEV)
+    tr = mireg.RegistrationTrainer(m, use_graph=False, autotune=False)
+    x4, x2 = make_pairs(4, 64, seed=1)[0].to(DEV), make_pairs(2, 64, seed=2)[0].to(DEV)
+    for _ in range(3):
+        tr.step(x4)
+    for _ in range(2):
+        tr.step(x2)
+    tr.step(x4)
+    counts = {k: int(v) for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")}
+    assert counts and all(v == 6 for v in counts.values()), counts
