@@ -163,6 +163,18 @@ int mireg_ssim(const float* a, const float* b, double* out, int B, int H, int W,
  * (row, col) float pairs (the contour points utils.py:154-170 extracts with skimage.measure.find_contours -- that extraction is
  * not part of this library); work = nA + nB floats; out = one float64. */
 int mireg_modified_hausdorff(const float* A, int nA, const float* B, int nB, float* work, double* out, hipStream_t stream);
+/* utils.py:155-170 extract_boundary_points on device for nmask binary masks seg == labels_dev[m] of (H, W) label maps seg_stride floats
+ * apart: the marching-squares vertices of skimage.measure.find_contours(mask, 0.5) truncated to int = one (row, col) point per
+ * 4-neighbour pixel pair with differing mask values, in raster order (deterministic).  counts[m] = number of points, points[m] =
+ * counts[m] (row, col) float pairs at points + m * points_stride (points_stride >= 4 * H * W floats).  rowcnt / rowoff: nmask * H ints.
+ * skimage repeats the first vertex of every closed contour; that duplicate is not reproduced (skimage absent: parity unpinned). */
+int mireg_boundary_points(const float* seg, long seg_stride, int nmask, const float* labels_dev, int H, int W, int* rowcnt, int* rowoff,
+                          int* counts, float* points, long points_stride, hipStream_t stream);
+/* utils.py:201-211 dist_hausdorff without a host round trip: pair p = modified Hausdorff distance of point sets 2p and 2p+1 of the
+ * buffers above (sizes read on device, at most cap points each); out[0] = mean over the pairs, out[1 + p] = the pairs' distances
+ * (float64; nan when a contour is empty, as numpy's mean of an empty set).  work: npair * 2 * cap floats. */
+int mireg_hausdorff_pairs(const float* points, long points_stride, const int* counts, int npair, int cap, float* work, double* out,
+                          hipStream_t stream);
 
 /* ---- K16-K18: the FlowNet2 stack's glue layers (flownet2/models.py:40-88,136-180) ----
  * Planar fp32 (B,C,H,W).  Resample2d and ChannelNorm are EXTERNAL custom layers of NVIDIA/flownet2-pytorch (sources absent
@@ -192,6 +204,18 @@ int mireg_elastic_sample(const float* img, const float* seg, const float* disp, 
  * (align_corners=False, zeros): bilinear for img, nearest for seg; theta (B,2,3) row-major; img or seg may be NULL. */
 int mireg_affine_sample2d(const float* img, const float* seg, const float* theta, float* out_img, float* out_seg, int B, int C,
                           int Cs, int H, int W, hipStream_t stream);
+
+/* ---- the front of the data pipeline on device (dataset.py:52-57,73-77,83 and 141-153): Transposed /
+ * SpatialCropd are views (base pointer + element strides per logical axis d, h, w), Resized = F.interpolate arithmetic (mode 0: linear,
+ * align_corners=False, over every axis whose extent changes; mode 1: nearest), Rotate90d = numpy.rot90(k) on the (h, w) axes.  in:
+ * N items of logical extent (D, H, W); out: N items of extent (d, h', w') with (h', w') = (h, w) for even k, (w, h) for odd k, written
+ * through the element strides (osn, osd, osh, osw).  The 2-D slice pipeline is D = d = number of slices (no interpolation along d). */
+int mireg_resample_volume(const float* in, long isn, long isd, long ish, long isw, int N, int D, int H, int W, float* out, long osn,
+                          long osd, long osh, long osw, int d, int h, int w, int mode, int rot_k, hipStream_t stream);
+/* ScaleIntensityd(minv, maxv) per item, in place: (x - min) / (max - min) * (maxv - minv) + minv over the item's n contiguous values
+ * (a constant item becomes x * minv, as MONAI does).  workspace: items * MIREG_SCALE_INTENSITY_BLOCKS * 2 floats. */
+#define MIREG_SCALE_INTENSITY_BLOCKS 64
+int mireg_scale_intensity(float* x, int items, long n, float minv, float maxv, float* workspace, hipStream_t stream);
 
 /* ---- K1-K4: implicit-GEMM convolution family on MFMA ------------------------------------- */
 /* One descriptor drives three contractions (all NHWC, pixel stride `ld` in elements, so producers
@@ -247,8 +271,8 @@ typedef struct mireg_conv_desc {
    * N*slab_ld apart */
   long slab_ld;
   /* mireg_conv_gemm / mireg_conv_wgrad kernel choice.  algo 0 = the halo-staged kernel (conv_halo.hip) whenever mireg_conv_halo_eligible says
-   * so, else the ring kernel; 1 = ring kernel; 2 = halo kernel or MIREG_ERR_UNSUPPORTED; 3 (mireg_conv_gemm only) = the 256-pixel
-   * 8-wave tile of conv_wide.hip (tile_n 128 / 256 columns, 0 = by N) or MIREG_ERR_UNSUPPORTED.  tile_m = pixels per halo tile
+   * so, else the ring kernel; 1 = ring kernel; 2 = halo kernel or MIREG_ERR_UNSUPPORTED; 3 = the 8-wave 256-row tiles (mireg_conv_gemm: conv_wide.hip,
+   * tile_n 128 / 256 columns, 0 = by N; mireg_conv_wgrad: conv_wgrad_wide.hip) or MIREG_ERR_UNSUPPORTED.  tile_m = pixels per halo tile
    * (0 = by tile count, 128 or 256 forces it). */
   int algo, tile_m;
 } mireg_conv_desc;
@@ -258,6 +282,9 @@ int mireg_conv_halo_eligible(const mireg_conv_desc* desc, long* tiles_out);
 /* 1 when mireg_conv_wgrad takes the halo-staged backward-weights kernel (conv_wgrad_halo.hip) for desc: bf16, square kernel,
  * stride 1 or 2 with every tap-parity class 3x3 / 3x2 / 2x3 / 2x2 (3x3 s1, 5x5 s2, 4x4 s2), dy grid 16 / 32 / 64 wide. */
 int mireg_conv_wgrad_halo_eligible(const mireg_conv_desc* desc);
+/* 1 when mireg_conv_wgrad can run desc on the 256 x 256 8-wave tile of conv_wgrad_wide.hip (algo 3): bf16, 2-D, more than 128 output
+ * channels. */
+int mireg_conv_wgrad_wide_eligible(const mireg_conv_desc* desc);
 /* 1 when algo 3 applies to desc (bf16, 2-D, x_C >= 64); tiles_out (may be NULL) = workgroups per class at the tile width
  * desc->tile_n selects. */
 int mireg_conv_wide_eligible(const mireg_conv_desc* desc, long* tiles_out);

@@ -148,6 +148,95 @@ affine_sample2d_kernel(const float* __restrict__ img, const float* __restrict__ 
   }
 }
 
+
+// ---- the front of the reference's data pipeline on device (dataset.py:52-57,73-77,141-148: Transposed -> SpatialCropd -> per-slice
+// Resized(bilinear | nearest) -> Rotate90d; volume_ds: Resized(trilinear) -> Rotate90d(k=2)) as ONE gather kernel: the source is
+// addressed through element strides per logical axis (so Transposed and the crop are views: a base pointer and strides), the
+// resize is torch's F.interpolate arithmetic (linear: align_corners=False, src = (dst + 0.5) * in/out - 0.5 clamped at 0;
+// nearest: src = floor(dst * in/out)), the rotation is numpy's rot90 on the last two logical axes.
+__device__ __forceinline__ void lin_tap(int dst, int in, int out, int& i0, int& i1, float& w1) {
+  if (in == out) { i0 = i1 = dst; w1 = 0.f; return; }
+  float sc = (float)in / (float)out;
+  float s = ((float)dst + 0.5f) * sc - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i0 = i0 > in - 1 ? in - 1 : i0;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+}
+__device__ __forceinline__ int near_tap(int dst, int in, int out) {
+  if (in == out) return dst;
+  const int i = (int)floorf((float)dst * ((float)in / (float)out));
+  return i > in - 1 ? in - 1 : i;
+}
+
+__global__ void __launch_bounds__(kThreads)
+resample_volume_kernel(const float* __restrict__ in, long isn, long isd, long ish, long isw, int N, int D, int H, int W,
+                       float* __restrict__ out, long osn, long osd, long osh, long osw, int d, int h, int w, int mode, int rot_k) {
+  // output extents after the rotation: (d, oh, ow) with (oh, ow) = (h, w) for even k, (w, h) for odd k
+  const int oh = (rot_k & 1) ? w : h, ow = (rot_k & 1) ? h : w;
+  const long total = (long)N * d * oh * ow;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(t % ow), i = (int)((t / ow) % oh), z = (int)((t / ((long)ow * oh)) % d);
+    const long n = t / ((long)ow * oh * d);
+    // numpy.rot90(m, k) on (h, w): k=1: out[i][j] = m[j][w-1-i]; k=2: m[h-1-i][w-1-j]; k=3: m[h-1-j][i]
+    int r, c;
+    switch (rot_k & 3) {
+      case 0: r = i; c = j; break;
+      case 1: r = j; c = w - 1 - i; break;
+      case 2: r = h - 1 - i; c = w - 1 - j; break;
+      default: r = h - 1 - j; c = i; break;
+    }
+    const float* src = in + n * isn;
+    float v;
+    if (mode == 1) {
+      v = src[(long)near_tap(z, D, d) * isd + (long)near_tap(r, H, h) * ish + (long)near_tap(c, W, w) * isw];
+    } else {
+      int z0, z1, y0, y1, x0, x1;
+      float wz, wy, wx;
+      lin_tap(z, D, d, z0, z1, wz); lin_tap(r, H, h, y0, y1, wy); lin_tap(c, W, w, x0, x1, wx);
+      auto at = [&](int zz, int yy, int xx) { return src[(long)zz * isd + (long)yy * ish + (long)xx * isw]; };
+      // torch's order: lerp along x, then y, then z
+      const float a00 = at(z0, y0, x0) * (1.f - wx) + at(z0, y0, x1) * wx, a01 = at(z0, y1, x0) * (1.f - wx) + at(z0, y1, x1) * wx;
+      const float a0 = a00 * (1.f - wy) + a01 * wy;
+      if (z1 == z0) v = a0;
+      else {
+        const float a10 = at(z1, y0, x0) * (1.f - wx) + at(z1, y0, x1) * wx, a11 = at(z1, y1, x0) * (1.f - wx) + at(z1, y1, x1) * wx;
+        v = a0 * (1.f - wz) + (a10 * (1.f - wy) + a11 * wy) * wz;
+      }
+    }
+    out[n * osn + (long)z * osd + (long)i * osh + (long)j * osw] = v;
+  }
+}
+
+// ScaleIntensityd(minv, maxv) per item (dataset.py:83,153,209): (x - min) / (max - min) * (maxv - minv) + minv over the item's n values;
+// a constant item becomes x * minv, as MONAI does.  Two launches: per-item partial extrema (fixed-order tree), then the map.
+__global__ void __launch_bounds__(kThreads)
+minmax_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {   // grid (blocks, items); part[item][block][2]
+  __shared__ float smin[kThreads], smax[kThreads];
+  const float* p = x + (long)blockIdx.y * n;
+  float lo = 3.4e38f, hi = -3.4e38f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { const float v = p[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int s2 = kThreads / 2; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2) { smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s2]); smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s2]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { float* o = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2; o[0] = smin[0]; o[1] = smax[0]; }
+}
+__global__ void __launch_bounds__(kThreads)
+scale_intensity_kernel(float* __restrict__ x, long n, const float* __restrict__ part, int nblk, float minv, float maxv) {
+  const float* pp = part + (long)blockIdx.y * nblk * 2;
+  float lo = 3.4e38f, hi = -3.4e38f;
+  for (int b = 0; b < nblk; ++b) { lo = fminf(lo, pp[2 * b]); hi = fmaxf(hi, pp[2 * b + 1]); }
+  float* p = x + (long)blockIdx.y * n;
+  const bool flat = hi == lo;
+  const float k = flat ? 0.f : (maxv - minv) / (hi - lo);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    p[i] = flat ? p[i] * minv : (p[i] - lo) * k + minv;
+}
+
 }  // namespace
 
 extern "C" {
@@ -175,6 +264,24 @@ int mireg_affine_sample2d(const float* img, const float* seg, const float* theta
   MIREG_CHECK_ARG((!img || (out_img && C > 0)) && (!seg || (out_seg && Cs > 0)));
   hipLaunchKernelGGL(affine_sample2d_kernel, dim3(grid_for((long)B * H * W)), dim3(kThreads), 0, stream, img, seg, theta, out_img,
                      out_seg, B, C, Cs, H, W);
+  MIREG_LAUNCH_RET();
+}
+
+
+int mireg_resample_volume(const float* in, long isn, long isd, long ish, long isw, int N, int D, int H, int W, float* out, long osn,
+                          long osd, long osh, long osw, int d, int h, int w, int mode, int rot_k, hipStream_t stream) {
+  MIREG_CHECK_ARG(in && out && N > 0 && D > 0 && H > 0 && W > 0 && d > 0 && h > 0 && w > 0 && (mode == 0 || mode == 1) && rot_k >= 0 && rot_k <= 3);
+  hipLaunchKernelGGL(resample_volume_kernel, dim3(grid_for((long)N * d * h * w)), dim3(kThreads), 0, stream, in, isn, isd, ish, isw, N, D, H, W,
+                     out, osn, osd, osh, osw, d, h, w, mode, rot_k);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_scale_intensity(float* x, int items, long n, float minv, float maxv, float* workspace, hipStream_t stream) {
+  MIREG_CHECK_ARG(x && workspace && items > 0 && n > 0);
+  int nblk = (int)((n + kThreads * 8 - 1) / (kThreads * 8));
+  nblk = nblk < 1 ? 1 : (nblk > MIREG_SCALE_INTENSITY_BLOCKS ? MIREG_SCALE_INTENSITY_BLOCKS : nblk);
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(nblk, items), dim3(kThreads), 0, stream, x, n, workspace);
+  hipLaunchKernelGGL(scale_intensity_kernel, dim3(nblk, items), dim3(kThreads), 0, stream, x, n, workspace, nblk, minv, maxv);
   MIREG_LAUNCH_RET();
 }
 

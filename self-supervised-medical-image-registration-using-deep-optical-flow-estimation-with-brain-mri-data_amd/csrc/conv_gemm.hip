@@ -982,6 +982,7 @@ bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
 extern "C" int mireg_conv_halo_try(const mireg_conv_desc* p, hipStream_t stream);         // conv_halo.hip
 extern "C" int mireg_conv_wgrad_halo_try(const mireg_conv_desc* p, hipStream_t stream);   // conv_wgrad_halo.hip
 extern "C" int mireg_conv_wide_try(const mireg_conv_desc* p, hipStream_t stream);         // conv_wide.hip
+extern "C" int mireg_conv_wgrad_wide_try(const mireg_conv_desc* p, hipStream_t stream);   // conv_wgrad_wide.hip
 
 extern "C" {
 
@@ -1007,6 +1008,10 @@ int mireg_conv_gemm(const mireg_conv_desc* desc, hipStream_t stream) {
 
 int mireg_conv_wgrad(const mireg_conv_desc* desc, hipStream_t stream) {
   if (!desc_ok(desc, true)) return MIREG_ERR_ARG;
+  if (desc->algo == 3) {                                            // 3: the 256 x 256 8-wave tile (conv_wgrad_wide.hip) or UNSUPPORTED
+    const int rc = mireg_conv_wgrad_wide_try(desc, stream);
+    return rc == -100 ? MIREG_ERR_UNSUPPORTED : rc;
+  }
   if (desc->algo != 1) {                                            // 0: halo-staged kernel when it applies, 2: require it
     const int rc = mireg_conv_wgrad_halo_try(desc, stream);
     if (rc != -100) return rc;

@@ -216,6 +216,107 @@ mhd_finalize_kernel(const float* __restrict__ work, int nA, int nB, double* __re
   }
 }
 
+
+// ---- contour points of a label mask (utils.py:155-170: skimage.measure.find_contours(mask, 0.5), vstack, astype(int)).  For a binary
+// mask the marching-squares vertices are the midpoints of the 4-neighbour pixel pairs whose mask values differ, (r, c + 0.5) and
+// (r + 0.5, c); truncated to int they are (r, c).  One point per crossing, in raster order (row, then horizontal before vertical
+// crossing per pixel): deterministic compaction = per-row counts, a single-block scan, per-row fill.  skimage additionally repeats the
+// first vertex of every closed contour; that duplicate is not reproduced (skimage is absent from this image: parity unpinned).
+__device__ __forceinline__ bool is_lab(const float* seg, int W, int r, int c, float lab) { return seg[(long)r * W + c] == lab; }
+
+__global__ void __launch_bounds__(kThreads)
+boundary_count_kernel(const float* __restrict__ seg, long sstride, int nmask, const float* __restrict__ labels, int H, int W, int* __restrict__ rowcnt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nmask * H) return;
+  const int m = t / H, r = t - m * H;
+  const float* sg = seg + (long)m * sstride;
+  const float lab = labels[m];
+  int n = 0;
+  for (int c = 0; c < W; ++c) {
+    const bool a = is_lab(sg, W, r, c, lab);
+    if (c + 1 < W && a != is_lab(sg, W, r, c + 1, lab)) ++n;
+    if (r + 1 < H && a != is_lab(sg, W, r + 1, c, lab)) ++n;
+  }
+  rowcnt[t] = n;
+}
+__global__ void __launch_bounds__(kThreads)
+boundary_scan_kernel(const int* __restrict__ rowcnt, int H, int* __restrict__ rowoff, int* __restrict__ total) {   // one block per mask
+  __shared__ int part[kThreads];
+  const int m = blockIdx.x;
+  const int per = (H + kThreads - 1) / kThreads, r0 = threadIdx.x * per, r1 = min(H, r0 + per);
+  int s = 0;
+  for (int r = r0; r < r1; ++r) s += rowcnt[m * H + r];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { int acc = 0; for (int k = 0; k < kThreads; ++k) { const int v = part[k]; part[k] = acc; acc += v; } total[m] = acc; }
+  __syncthreads();
+  int acc = part[threadIdx.x];
+  for (int r = r0; r < r1; ++r) { rowoff[m * H + r] = acc; acc += rowcnt[m * H + r]; }
+}
+__global__ void __launch_bounds__(kThreads)
+boundary_fill_kernel(const float* __restrict__ seg, long sstride, int nmask, const float* __restrict__ labels, int H, int W,
+                     const int* __restrict__ rowoff, float* __restrict__ pts, long pstride) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nmask * H) return;
+  const int m = t / H, r = t - m * H;
+  const float* sg = seg + (long)m * sstride;
+  const float lab = labels[m];
+  float* o = pts + (long)m * pstride + 2L * rowoff[t];
+  for (int c = 0; c < W; ++c) {
+    const bool a = is_lab(sg, W, r, c, lab);
+    if (c + 1 < W && a != is_lab(sg, W, r, c + 1, lab)) { o[0] = (float)r; o[1] = (float)c; o += 2; }
+    if (r + 1 < H && a != is_lab(sg, W, r + 1, c, lab)) { o[0] = (float)r; o[1] = (float)c; o += 2; }
+  }
+}
+// modified Hausdorff distance of point sets whose sizes live on the device (no host round trip between extraction and distance)
+__global__ void __launch_bounds__(kThreads)
+mhd_nearest_dev_kernel(const float* __restrict__ A, const float* __restrict__ Bp, long pstride, const int* __restrict__ cnt, int npair, int cap,
+                       float* __restrict__ work) {                   // grid (blocks, pairs): pair p uses masks 2p (A) and 2p+1 (B)
+  const int p = blockIdx.y;
+  const int nA = min(cnt[2 * p], cap), nB = min(cnt[2 * p + 1], cap);
+  const float* a = A + (long)(2 * p) * pstride;
+  const float* b = Bp + (long)(2 * p + 1) * pstride;
+  float* wk = work + (long)p * 2 * cap;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB; i += gridDim.x * blockDim.x) {
+    const bool fromA = i < nA;
+    const float* me = fromA ? a + 2 * i : b + 2 * (i - nA);
+    const float* other = fromA ? b : a;
+    const int n = fromA ? nB : nA;
+    const float y = me[0], x = me[1];
+    float best = 3.4e38f;
+    for (int j = 0; j < n; ++j) { const float dy = other[2 * j] - y, dx = other[2 * j + 1] - x; best = fminf(best, dy * dy + dx * dx); }
+    wk[fromA ? i : cap + (i - nA)] = sqrtf(best);
+  }
+}
+__global__ void __launch_bounds__(kThreads)
+mhd_finalize_dev_kernel(const float* __restrict__ work, const int* __restrict__ cnt, int npair, int cap, double* __restrict__ out) {
+  __shared__ double red[2][kThreads / 64];
+  __shared__ double acc_mean;
+  if (threadIdx.x == 0) acc_mean = 0.0;
+  __syncthreads();
+  for (int p = 0; p < npair; ++p) {
+    const int nA = min(cnt[2 * p], cap), nB = min(cnt[2 * p + 1], cap);
+    const float* wk = work + (long)p * 2 * cap;
+    double sa = 0.0, sb = 0.0;
+    for (int i = threadIdx.x; i < nA; i += blockDim.x) sa += (double)wk[i];
+    for (int i = threadIdx.x; i < nB; i += blockDim.x) sb += (double)wk[cap + i];
+    sa = wave_sum(sa); sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sa; red[1][threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double ta = 0.0, tb = 0.0;
+      for (int k = 0; k < kThreads / 64; ++k) { ta += red[0][k]; tb += red[1][k]; }
+      // an empty contour on either side: numpy's mean of an empty min() is nan in the reference; reported as nan here too
+      const double rhd = nA > 0 && nB > 0 ? ta / (double)nA : __longlong_as_double(0x7ff8000000000000LL);
+      const double fhd = nA > 0 && nB > 0 ? tb / (double)nB : __longlong_as_double(0x7ff8000000000000LL);
+      out[1 + p] = fhd > rhd ? fhd : rhd;
+      acc_mean += out[1 + p];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = acc_mean / (double)npair;
+}
+
 }  // namespace
 
 extern "C" {
@@ -261,6 +362,27 @@ int mireg_modified_hausdorff(const float* A, int nA, const float* B, int nB, flo
   MIREG_CHECK_ARG(A && B && work && out && nA > 0 && nB > 0);
   hipLaunchKernelGGL(mhd_nearest_kernel, dim3((nA + nB + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, A, nA, B, nB, work);
   hipLaunchKernelGGL(mhd_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, work, nA, nB, out);
+  MIREG_LAUNCH_RET();
+}
+
+
+int mireg_boundary_points(const float* seg, long seg_stride, int nmask, const float* labels_dev, int H, int W, int* rowcnt, int* rowoff,
+                          int* counts, float* points, long points_stride, hipStream_t stream) {
+  MIREG_CHECK_ARG(seg && labels_dev && rowcnt && rowoff && counts && points && nmask > 0 && H > 0 && W > 0 && points_stride >= 4L * H * W);
+  const int g = (nmask * H + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(boundary_count_kernel, dim3(g), dim3(kThreads), 0, stream, seg, seg_stride, nmask, labels_dev, H, W, rowcnt);
+  hipLaunchKernelGGL(boundary_scan_kernel, dim3(nmask), dim3(kThreads), 0, stream, rowcnt, H, rowoff, counts);
+  hipLaunchKernelGGL(boundary_fill_kernel, dim3(g), dim3(kThreads), 0, stream, seg, seg_stride, nmask, labels_dev, H, W, rowoff, points, points_stride);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_hausdorff_pairs(const float* points, long points_stride, const int* counts, int npair, int cap, float* work, double* out,
+                          hipStream_t stream) {
+  MIREG_CHECK_ARG(points && counts && work && out && npair > 0 && cap > 0 && points_stride >= 2L * cap);
+  int g = (2 * cap + kThreads - 1) / kThreads;
+  g = g > 64 ? 64 : g;
+  hipLaunchKernelGGL(mhd_nearest_dev_kernel, dim3(g, npair), dim3(kThreads), 0, stream, points, points, points_stride, counts, npair, cap, work);
+  hipLaunchKernelGGL(mhd_finalize_dev_kernel, dim3(1), dim3(kThreads), 0, stream, work, counts, npair, cap, out);
   MIREG_LAUNCH_RET();
 }
 

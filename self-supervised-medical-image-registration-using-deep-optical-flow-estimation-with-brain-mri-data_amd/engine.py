@@ -610,9 +610,10 @@ class ConvLayer:
         elif self._wgrad_key(x, dy) in self.ws.tuned_wgrad:
             tw = self.ws.tuned_wgrad[self._wgrad_key(x, dy)]
             self.wgrad_split, self.wgrad_algo = (tw, 0) if isinstance(tw, int) else (tw[0], tw[1])
-            if self.wgrad_algo == 2:                          # a cached "halo kernel" choice must still apply to these operands
+            if self.wgrad_algo in (2, 3):                     # a cached kernel choice must still apply to these operands
                 probe = self._wgrad_desc(x, dy, 1, 0, 0)
-                if not _lib.lib().mireg_conv_wgrad_halo_eligible(ctypes.byref(probe)):
+                ok = (_lib.lib().mireg_conv_wgrad_halo_eligible if self.wgrad_algo == 2 else _lib.lib().mireg_conv_wgrad_wide_eligible)
+                if not ok(ctypes.byref(probe)):
                     self.wgrad_algo = 0
             self.wgrad_split = max(1, min(self.wgrad_split, max(nk // 8, 1)))
             self._wgrad_tuned = True
@@ -662,7 +663,10 @@ class ConvLayer:
         if halo:
             tiles = ((self.Co + 127) // 128) * ((self.Cip + 31) // 32) * self.s * self.s
             cands += [(sp, 2) for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if sp <= max(dy.rows // 512, 1) and 96 <= tiles * sp <= 1536]
-        if WGRAD_ALGO != 2:
+        if USE_WIDE and WGRAD_ALGO in (0, 3) and bool(_lib.lib().mireg_conv_wgrad_wide_eligible(ctypes.byref(probe))):
+            tiles = ((self.Co + 255) // 256) * ((self.Kf + 255) // 256)     # the 256 x 256 8-wave tile (conv_wgrad_wide.hip)
+            cands += [(sp, 3) for sp in (1, 2, 3, 4, 6, 8, 11, 16, 22, 32, 44, 64) if sp <= max(nk // 8, 1) and 64 <= tiles * sp <= 1024]
+        if WGRAD_ALGO not in (2, 3):
             tiles = ((self.Co + 127) // 128) * ((self.Kf + 127) // 128)
             # one- and two-tile launches (PWC's 16- and 32-channel pyramid layers over 128x128 maps) get all their parallelism from
             # the pixel split: up to 768 ways
@@ -724,8 +728,8 @@ class ConvLayer:
         if self.ws.tuning and not getattr(self, "_wgrad_tuned", False):
             self._tune_wgrad(x, dy)
         d = self._wgrad_desc(x, dy, self.wgrad_split, self.wgrad_slab[slot * self.wgrad_split].data_ptr())
-        halo = d.algo != 1 and bool(_lib.lib().mireg_conv_wgrad_halo_eligible(ctypes.byref(d)))
-        PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_halo_kernel" if halo else "conv_wgrad_kernel<128,128>",
+        halo = d.algo not in (1, 3) and bool(_lib.lib().mireg_conv_wgrad_halo_eligible(ctypes.byref(d)))
+        PROFILER.launch("mireg_conv_wgrad", d, "conv_wgrad_wide_kernel<256,256>" if d.algo == 3 else ("conv_wgrad_halo_kernel" if halo else "conv_wgrad_kernel<128,128>"),
                         2.0 * dy.rows * self.Co * self.kh * self.kw * self.Ci,
                         f"{self.name}:wgrad M={self.Co} N={self.Kf} K={dy.rows} split={d.split_k}")
 

@@ -101,3 +101,43 @@ def modified_hausdorff(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     out = torch.empty(1, device=A.device, dtype=torch.float64)
     _lib.call("mireg_modified_hausdorff", A.data_ptr(), A.shape[0], B.data_ptr(), B.shape[0], work.data_ptr(), out.data_ptr(), _stream())
     return out[0]
+
+
+def extract_boundary_points(mask: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference utils.extract_boundary_points (utils.py:155-170) on a binary (H, W) device mask: the (row, col) points of
+    skimage.measure.find_contours(mask, 0.5) truncated to int, one per 4-neighbour pixel pair with differing values (raster order;
+    skimage's repeated first vertex of closed contours is not reproduced).  Returns an (n, 2) float tensor (this call reads n back)."""
+    pts, cnt = _boundary_sets(mask.float().unsqueeze(0), torch.ones(1, device=mask.device))
+    return pts[0, :int(cnt[0])]
+
+
+def _boundary_sets(segs: torch.Tensor, labels: torch.Tensor):
+    """segs (m, H, W) fp32 label maps, labels (m,) -> (points (m, 2HW, 2), counts (m,) int32), all on device."""
+    _need_gpu(segs, labels)
+    segs, labels = segs.contiguous().float(), labels.contiguous().float()
+    m, H, W = segs.shape
+    dev = segs.device
+    rowcnt = torch.empty(m * H, device=dev, dtype=torch.int32)
+    rowoff = torch.empty(m * H, device=dev, dtype=torch.int32)
+    counts = torch.empty(m, device=dev, dtype=torch.int32)
+    pts = torch.empty(m, 2 * H * W, 2, device=dev, dtype=torch.float32)
+    _lib.call("mireg_boundary_points", segs.data_ptr(), H * W, m, labels.data_ptr(), H, W, rowcnt.data_ptr(), rowoff.data_ptr(),
+              counts.data_ptr(), pts.data_ptr(), 4 * H * W, _stream())
+    return pts, counts
+
+
+def dist_hausdorff(seg1: torch.Tensor, seg2: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference utils.dist_hausdorff (utils.py:201-211): mean over the labels 1..3 of the modified Hausdorff distance between
+    the contour points of seg1 == label and seg2 == label; (H, W) device label maps in, float64 device scalar out.  Contour
+    extraction, nearest-point search and the means all run on device without a host round trip (inference.py:66-75 calls this per
+    sample; the reference goes through .cpu().numpy() and skimage three times per call)."""
+    _need_gpu(seg1, seg2)
+    H, W = seg1.shape[-2:]
+    segs = torch.stack([seg1.reshape(H, W).float(), seg2.reshape(H, W).float()] * 3)          # masks 2p, 2p+1 = pair p
+    labels = torch.tensor([1, 1, 2, 2, 3, 3], device=seg1.device, dtype=torch.float32)
+    pts, counts = _boundary_sets(segs, labels)
+    cap = 2 * H * W
+    work = torch.empty(3 * 2 * cap, device=seg1.device, dtype=torch.float32)
+    out = torch.empty(4, device=seg1.device, dtype=torch.float64)
+    _lib.call("mireg_hausdorff_pairs", pts.data_ptr(), 4 * H * W, counts.data_ptr(), 3, cap, work.data_ptr(), out.data_ptr(), _stream())
+    return out[0]

@@ -89,3 +89,80 @@ def affine_deform(images: torch.Tensor, segs, theta: torch.Tensor):
               out.data_ptr(), out_seg.data_ptr() if out_seg is not None else None, B, C, segs.shape[1] if segs is not None else 0,
               H, W, _stream())
     return out, out_seg
+
+
+def _strides3(t: torch.Tensor):
+    """Element strides (item, d, h, w) of an (N, D, H, W) view (any permutation / crop of a contiguous volume)."""
+    return t.stride(0), t.stride(1), t.stride(2), t.stride(3)
+
+
+def resample_volume(vol: torch.Tensor, size, mode: str = "bilinear", rot_k: int = 0) -> torch.Tensor:
+    """Resized + Rotate90d of the reference's MONAI pipelines on device.  vol: (N, D, H, W) fp32 VIEW of device memory (Transposed and
+    SpatialCropd of dataset.py:55-56,143-145 are `permute` / slicing on the caller's side: only strides change); size = (d, h, w)
+    after the resize (d == D for the per-slice 2-D pipeline); mode "bilinear" (torch's linear interpolation with
+    align_corners=False over every resized axis) or "nearest"; rot_k = numpy.rot90 k on the (h, w) axes.  Returns a contiguous
+    (N, d, h', w')."""
+    from . import _lib
+    from .ops import _need_gpu, _stream
+    _need_gpu(vol)
+    if vol.dim() != 4 or vol.dtype != torch.float32:
+        raise RuntimeError(f"resample_volume expects an (N, D, H, W) float32 view, got {tuple(vol.shape)} {vol.dtype}")
+    N, D, H, W = vol.shape
+    d, h, w = (int(v) for v in size)
+    oh, ow = (w, h) if rot_k % 2 else (h, w)
+    out = torch.empty(N, d, oh, ow, device=vol.device, dtype=torch.float32)
+    _lib.call("mireg_resample_volume", vol.data_ptr(), *_strides3(vol), N, D, H, W, out.data_ptr(), *_strides3(out), d, h, w,
+              {"bilinear": 0, "trilinear": 0, "nearest": 1}[mode], rot_k % 4, _stream())
+    return out
+
+
+def scale_intensity(x: torch.Tensor, minv: float = 0.0, maxv: float = 1.0) -> torch.Tensor:
+    """ScaleIntensityd(minv, maxv) per item of a contiguous (N, ...) fp32 batch, in place (dataset.py:83,153,209)."""
+    from . import _lib
+    from .ops import _need_gpu, _stream
+    _need_gpu(x)
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise RuntimeError("scale_intensity expects a contiguous float32 batch")
+    n = x[0].numel()
+    ws = torch.empty(x.shape[0] * 64 * 2, device=x.device, dtype=torch.float32)
+    _lib.call("mireg_scale_intensity", x.data_ptr(), x.shape[0], n, float(minv), float(maxv), ws.data_ptr(), _stream())
+    return x
+
+
+def slices_from_volume(image: torch.Tensor, seg=None, z_range=(60, 140), yx_size=(176, 208), size: int = 256, rot_k: int = 1):
+    """The volume -> slice front of volume2slices_ds / eval_random_ds (dataset.py:52-57,73-77) on device: image / seg are the
+    Transposed volumes (Z, Y, X) fp32 on the GPU; SpatialCropd(roi_start=(z0, 0, 0), roi_end=(z1, Y, X)), one patch per slice,
+    Resized to (size, size) (image bilinear, label map nearest), Rotate90d(k).  Returns (slices (n, 1, size, size), seg slices or
+    None); the per-pair steps that follow (elastic_deform, concat, scale_intensity) are the other functions of this module."""
+    z0, z1 = z_range
+    crop = image[z0:z1, :yx_size[0], :yx_size[1]]
+    out = resample_volume(crop.unsqueeze(0), (crop.shape[0], size, size), "bilinear", rot_k)[0].unsqueeze(1)
+    out_seg = None
+    if seg is not None:
+        cs = seg[z0:z1, :yx_size[0], :yx_size[1]]
+        out_seg = resample_volume(cs.unsqueeze(0), (cs.shape[0], size, size), "nearest", rot_k)[0].unsqueeze(1)
+    return out, out_seg
+
+
+def prepare_volume(image: torch.Tensor, size=(256, 256, 176), rot_k: int = 2) -> torch.Tensor:
+    """volume_ds (dataset.py:141-148) on device: image = the Transposed volume (A0, A1, A2) fp32 on the GPU; Resized(size, trilinear,
+    align_corners=False) and Rotate90d(k, spatial_axes=(0, 1)).  Returns (1, s0', s1', s2) contiguous in MONAI's axis order."""
+    # the kernel rotates its last two logical axes: present the volume as (d, h, w) = (A2, A0, A1) through a permuted view
+    v = image.permute(2, 0, 1).unsqueeze(0)
+    out = resample_volume(v, (size[2], size[0], size[1]), "trilinear", rot_k)          # (1, s2, s0', s1')
+    return out.permute(0, 2, 3, 1).contiguous()
+
+
+def affine_deform3d(vol: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
+    """The RandAffined step of volume_ds (dataset.py:150-152) as torch states it: F.grid_sample(vol, F.affine_grid(theta, vol.size()))
+    with trilinear interpolation, zero padding, align_corners=False; vol (B, C, D, H, W) fp32, theta (B, 3, 4)."""
+    from . import _lib
+    from .ops import _need_gpu, _stream
+    _need_gpu(vol, theta)
+    B, C, D, H, W = vol.shape
+    if tuple(theta.shape) != (B, 3, 4):
+        raise RuntimeError(f"affine_deform3d: theta {tuple(theta.shape)} does not match a batch of {B}")
+    vol, theta = vol.contiguous().float(), theta.contiguous().float()
+    out = torch.empty_like(vol)
+    _lib.call("mireg_affine_sample3d", vol.data_ptr(), theta.data_ptr(), out.data_ptr(), B, C, D, H, W, _stream())
+    return out

@@ -152,7 +152,7 @@ def test_flownetc_batch24_and_pwc_batch48_train_step_graph_autotune_vs_oracle(na
         vals = oops.ofe_loss(flows, warped, x[:, 0:1])
         opt.zero_grad(); vals[3].backward()
         if st == 0:
-            g32 = {k: p.grad.detach().double().clone() for k, p in om.named_parameters()}
+            g32 = {k: p.grad.detach().double().clone() for k, p in om.named_parameters() if p.grad is not None}
         opt.step()
         ref_losses.append([float(v) for v in vals])
     o64 = nets.OpticalFlowReg(name)
@@ -160,7 +160,7 @@ def test_flownetc_batch24_and_pwc_batch48_train_step_graph_autotune_vs_oracle(na
     o64 = o64.double().train()
     f64, w64, _, _ = o64(x.double())
     oops.ofe_loss(f64, w64, x[:, 0:1].double())[3].backward()
-    g64 = {k: p.grad.detach().clone() for k, p in o64.named_parameters()}
+    g64 = {k: p.grad.detach().clone() for k, p in o64.named_parameters() if p.grad is not None}
 
     tr = mireg.RegistrationTrainer(model.to(DEV), use_graph=True, autotune=True)
     xd = x.to(DEV)
@@ -168,7 +168,7 @@ def test_flownetc_batch24_and_pwc_batch48_train_step_graph_autotune_vs_oracle(na
     torch.cuda.synchronize()
     eng = tr.eng
     pname = {id(p): k for k, p in model.named_parameters()}
-    lays = [l for l in eng.layers.values() if l.wgrad_slab is not None and l.Co * l.Kf >= 4096]
+    lays = [l for l in eng.layers.values() if l.wgrad_slab is not None and l.Co * l.Kf >= 4096 and pname[id(l.weight)] in g64]
     picks = [lays[i] for i in sorted({0, 1, len(lays) // 4, len(lays) // 2, (3 * len(lays)) // 4, len(lays) - 2, len(lays) - 1})]
     report = {}
     for lay in picks:
@@ -180,7 +180,7 @@ def test_flownetc_batch24_and_pwc_batch48_train_step_graph_autotune_vs_oracle(na
         rel = ((a - b64).norm() / b64.norm()).item()
         cos = (torch.dot(a.flatten(), b64.flatten()) / (a.norm() * b64.norm())).item()
         report[k] = (rel, noise, cos)
-        assert rel <= 5e-3 + 8 * noise and cos >= 0.999, (k, rel, noise, cos)
+        assert rel <= min(5e-3 + 8 * noise, 5e-2) and cos >= 0.999, (k, rel, noise, cos)
     print(name, "gradient (rel L2 vs fp64 oracle, oracle-fp32 noise, cosine):", report)
     for _ in range(2):                                       # step 2 eager, step 3 captures the graphs and replays them
         got_losses.append(tr.step(xd).tolist())

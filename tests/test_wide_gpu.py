@@ -123,3 +123,42 @@ def test_wide_kernel_is_refused_where_it_does_not_apply():
                 lay.run_fwd_form(xv, yv)
         finally:
             engine.FORCE_ALGO = None
+
+
+WGRAD_CASES = [  # cin, cout, k, stride, pad, H, W, B
+    (256, 256, 3, 1, 1, 32, 32, 2),       # conv3_1 shape: one 256-row tile, 9 column tiles, split over pixels
+    (128, 256, 5, 2, 2, 32, 32, 3),       # conv3 shape (5x5 stride 2)
+    (512, 1024, 3, 1, 1, 4, 4, 6),        # conv6_1-like: 96 pixels = 3 K-steps, no split (the slab is the gradient)
+    (200, 386, 3, 1, 1, 12, 10, 2),       # ragged rows (386 = 256 + 130), ragged columns, ragged pixel count (240 = 7.5 K-steps)
+    (72, 136, 4, 2, 1, 16, 16, 2),        # 4x4 stride 2 (the deconvolutions' adjoint), 136 output channels: one half-empty tile
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wide_backward_weights(case):
+    """conv_wgrad_wide.hip (mireg_conv_wgrad, algo 3) against torch's weight gradient on the same bf16-rounded operands and against the
+    128 x 128 ring kernel (algo 1): same slab layout, same pixel splits."""
+    from mireg import engine
+    from mireg.engine import ConvLayer, Workspace, run_pack, run_unpack
+    cin, cout, k, s, p, H, W, B = case
+    ws = Workspace(torch.device(DEV), torch.bfloat16)
+    g = torch.Generator().manual_seed(cin + cout + k)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+    dy = torch.randn(B, cout, Ho, Wo, generator=g).bfloat16().float()
+    w = torch.zeros(cout, cin, k, k, requires_grad=True)
+    F.conv2d(x, w, None, s, p).backward(dy)
+    ref = w.grad.clone()
+    outs = {}
+    for tag, algo, split in (("ring", 1, 1), ("wide", 3, 1), ("wide-split3", 3, 3), ("ring-split3", 1, 3)):
+        lay = ConvLayer("t", torch.zeros(cout, cin, k, k, device=DEV), None, s, p, 1, ws)
+        lay.wgrad_split, lay.wgrad_algo = split, algo
+        lay.wgrad_slab = torch.zeros(split, lay.Co, lay.Kf, device=DEV, dtype=torch.float32)
+        lay.grad_w = torch.zeros_like(lay.weight)
+        xv, gv = _view_from(x.to(DEV), ws), _view_from(dy.to(DEV), ws)
+        lay.run_wgrad(xv, gv)
+        run_unpack([lay.unpack_job()], DEV)
+        torch.cuda.synchronize()
+        outs[tag] = lay.grad_w.float().cpu()
+        assert _rel(outs[tag], ref) < 2e-3, (tag, _rel(outs[tag], ref))        # fp32 accumulation of exact bf16 products: order only
+    assert _rel(outs["wide"], outs["ring"]) < 1e-4 and _rel(outs["wide-split3"], outs["ring-split3"]) < 1e-4
