@@ -20,7 +20,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import PROFILER, ConvDesc, Pack3dJob, PackJob, View, WoptJob, Workspace, _stream, assign_tiles, rup, upload_table
+from . import engine as engine_mod
+from .engine import DT_BF16, PROFILER, ConvDesc, Pack3dJob, PackJob, View, WoptJob, Workspace, _stream, assign_tiles, rup, upload_table
 from .ops import SLOTS
 
 SPEC = [(2, 16, 7, (2, 2, 1)), (16, 32, 5, (2, 2, 1)), (32, 64, 3, (2, 2, 2)), (64, 128, 3, (2, 2, 2)),
@@ -67,6 +68,9 @@ class Vol:
 
 def _vol(x, dims) -> Vol:
     return x if isinstance(x, Vol) else Vol(x, tuple(dims), x.shape[-1], 0)
+
+
+FORCE_WIDE = None      # tests only: None = heuristic, (128,) / (256,) = always the 256-pixel tile at that width, () = never
 
 
 class Conv3dLayer:
@@ -125,6 +129,16 @@ class Conv3dLayer:
         tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
         nk = (K + 31) // 32
         d.split_k = 1
+        # volumes have the rows the 256-pixel 8-wave tile (conv_wide.hip) wants: take it wherever its grid still covers the chip
+        # (FORCE_WIDE: tests; (tile_n,) forces it, () forbids it)
+        d.algo, d.tile_n = 0, 0
+        if self.ws.code == DT_BF16 and engine_mod.USE_WIDE and FORCE_WIDE != () and _lib.lib().mireg_conv_wide_eligible(ctypes.byref(d), None):
+            t256, t128 = ((M + 255) // 256) * ((N + 255) // 256), ((M + 255) // 256) * ((N + 127) // 128)
+            pick = FORCE_WIDE[0] if FORCE_WIDE else (256 if (N > 128 and t256 >= 224) else (128 if t128 >= 224 else 0))
+            if pick:
+                d.algo, d.tile_n = 3, pick
+                PROFILER.launch("mireg_conv_gemm", d, "conv3d_gemm", 2.0 * M * N * K, f"{getattr(self, 'name', 'conv3d')} M={M} N={N} K={K} wide{pick}")
+                return
         if tiles < 256 and nk >= 16:                        # deep / tiny layers (incl. the Linear): split K
             split = max(1, min((512 + tiles - 1) // tiles, nk // 4, 64))
             if split > 1:

@@ -88,8 +88,10 @@ conv_wide_kernel(const mireg_conv_desc pd) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;                                // ping-pong group: waves 0-3 / 4-7 = one wave of each SIMD
-  const int gHW = p.g_H * p.g_W;
-  const int M = p.n_img * gHW;
+  // optional depth axis (Conv3d): all *_D / *_z fields are 0 for 2-D launches and then collapse to extent 1
+  const int xD = max(p.x_D, 1), gD = max(p.g_D, 1), tapsZ = max(p.taps_z, 1), yD = max(p.y_D, 1), ymz = max(p.y_mul_z, 1);
+  const int gHW = p.g_H * p.g_W, gDHW = gD * gHW;
+  const int M = p.n_img * gDHW;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
   int bid = blockIdx.x;
   {   // XCD-aware tile order (blocks b, b+8, .. share an XCD): each XCD gets a contiguous run of tiles
@@ -101,7 +103,7 @@ conv_wide_kernel(const mireg_conv_desc pd) {
   if (M < p.N) { tile_n = bid / tiles_m; tile_m = bid - tile_n * tiles_m; }
   else { tile_m = bid / tiles_n; tile_n = bid - tile_m * tiles_n; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int K = p.taps_y * p.taps_x * p.x_C;
+  const int K = tapsZ * p.taps_y * p.taps_x * p.x_C;
   const int nk_total = (K + 63) / 64;
   int kt_begin = 0, kt_end = nk_total;
   if (p.split_k > 1) {
@@ -116,17 +118,20 @@ conv_wide_kernel(const mireg_conv_desc pd) {
   const int lrow = lane >> 3;
   const int kc = (lane & 7) ^ ((4 * wid + (lane >> 4)) & 7);       // logical 16-B chunk of the K-step this lane fetches
   const int ldb = (int)p.x_ld * 2;                                   // bytes per input pixel
-  int a_pix[4], a_iy0[4], a_ix0[4];                                  // byte offset of (img, iy0, ix0) (mod 2^32), tap-0 coordinates
+  int a_pix[4], a_iz0[4], a_iy0[4], a_ix0[4];                       // byte offset of (img, iz0, iy0, ix0) (mod 2^32), tap-0 coordinates
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int m = m0 + 8 * wid + 64 * c + lrow;
     const bool ok = m < M;
     const int mm = ok ? m : 0;
-    const int img = mm / gHW, rem = mm - img * gHW;
+    const int img = mm / gDHW, r3 = mm - img * gDHW;
+    const int gz = r3 / gHW, rem = r3 - gz * gHW;
     const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
+    a_iz0[c] = gz * p.mul_z + p.off_z;
     a_iy0[c] = ok ? gy * p.mul_y + p.off_y : -(1 << 28);             // rows past M never pass the range test
     a_ix0[c] = gx * p.mul_x + p.off_x;
-    a_pix[c] = (int)((unsigned)((long)img * p.x_H * p.x_W * ldb) + (unsigned)(((gy * p.mul_y + p.off_y) * p.x_W + a_ix0[c]) * ldb));
+    a_pix[c] = (int)((unsigned)((long)img * xD * p.x_H * p.x_W * ldb) +
+                     (unsigned)(((a_iz0[c] * p.x_H + (gy * p.mul_y + p.off_y)) * p.x_W + a_ix0[c]) * ldb));
   }
   unsigned b_base[NBC];
 #pragma unroll
@@ -135,23 +140,26 @@ conv_wide_kernel(const mireg_conv_desc pd) {
     b_base[c] = n < p.N ? (unsigned)((long)n * p.w_ld * 2) : kOOB;
   }
   const int cpt = p.x_C >> 3;                                       // 16-B chunks per tap (>= 8: at most one tap step per K-step)
-  int ty, tx, cc;
+  int tz, ty, tx, cc;
   {
     const int q = kt_begin * 8 + kc;
     const int tap = q / cpt;
     cc = q - tap * cpt;
-    ty = tap / p.taps_x;
-    tx = tap - ty * p.taps_x;
+    const int tyx = p.taps_y * p.taps_x;
+    tz = tap / tyx;
+    const int t2 = tap - tz * tyx;
+    ty = t2 / p.taps_x;
+    tx = t2 - ty * p.taps_x;
   }
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
   // per-tap quantities of this lane: coordinate shifts, byte shift; a_cur[c] = source byte offset of row c at the current tap
-  int dyv = ty * p.step_y, dxv = tx * p.step_x, tap_off = (dyv * p.x_W + dxv) * ldb;
+  int dzv = tz * p.step_z, dyv = ty * p.step_y, dxv = tx * p.step_x, tap_off = ((dzv * p.x_H + dyv) * p.x_W + dxv) * ldb;
   unsigned a_cur[4];
   bool tap_moved = true;                                              // wave-uniform: some lane stepped to a new tap
   auto row_update = [&](int c) {
-    const int iy = a_iy0[c] + dyv, ix = a_ix0[c] + dxv;
-    const bool ok = ty < p.taps_y && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
+    const int iz = a_iz0[c] + dzv, iy = a_iy0[c] + dyv, ix = a_ix0[c] + dxv;
+    const bool ok = tz < tapsZ && (unsigned)iz < (unsigned)xD && (unsigned)iy < (unsigned)p.x_H && (unsigned)ix < (unsigned)p.x_W;
     a_cur[c] = ok ? (unsigned)(a_pix[c] + tap_off) : kOOB;
   };
 #pragma unroll
@@ -175,8 +183,11 @@ conv_wide_kernel(const mireg_conv_desc pd) {
       const bool wx = tx >= p.taps_x;
       tx = wx ? 0 : tx;
       ty += wx ? 1 : 0;
-      dyv = ty * p.step_y; dxv = tx * p.step_x;
-      tap_off = (dyv * p.x_W + dxv) * ldb;
+      const bool wy = ty >= p.taps_y;
+      ty = wy ? 0 : ty;
+      tz += wy ? 1 : 0;
+      dzv = tz * p.step_z; dyv = ty * p.step_y; dxv = tx * p.step_x;
+      tap_off = ((dzv * p.x_H + dyv) * p.x_W + dxv) * ldb;
     }
   };
   auto rows_if_moved = [&](int c0, int c1) { if (tap_moved) { row_update(c0); row_update(c1); } };
@@ -305,9 +316,10 @@ conv_wide_kernel(const mireg_conv_desc pd) {
     if (m < M) {
       if (slab_out) off = ((long)blockIdx.z * M + m) * p.N;
       else {
-        const int img = m / gHW, rem = m - img * gHW;
+        const int img = m / gDHW, r3 = m - img * gDHW;
+        const int gz = r3 / gHW, rem = r3 - gz * gHW;
         const int gy = rem / p.g_W, gx = rem - gy * p.g_W;
-        off = ((long)img * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
+        off = (((long)img * yD + gz * ymz + p.y_off_z) * p.y_H + gy * p.y_mul_y + p.y_off_y) * p.y_W + gx * p.y_mul_x + p.y_off_x;
       }
     }
     rowoff[tid] = off;
@@ -398,20 +410,21 @@ conv_wide_kernel(const mireg_conv_desc pd) {
 
 }  // namespace
 
-// 1 when the wide kernel can run desc (bf16, 2-D, at least 64 channels per tap so that a lane's chunk steps at most one tap
+// 1 when the wide kernel can run desc (bf16, 2-D or single-class 3-D, at least 64 channels per tap so that a lane's chunk steps at most one tap
 // per K-step); tiles_out = workgroups per class at the tile width it would use (tile_n 128 / 256, 0 = by N).
 extern "C" int mireg_conv_wide_eligible(const mireg_conv_desc* p, long* tiles_out) {
   if (tiles_out) *tiles_out = 0;
   if (!p || p->dtype != MIREG_DTYPE_BF16) return 0;
-  if (p->x_D > 1 || p->g_D > 1 || p->taps_z > 1 || p->y_D > 1 || p->off_z != 0 || p->y_off_z != 0) return 0;
+  const bool depth = p->x_D > 1 || p->g_D > 1 || p->taps_z > 1 || p->y_D > 1;
+  if (depth && p->n_cls > 1) return 0;                               // Conv3d backward-data: one launch per parity class
   if (p->x_C < 64 || p->N < 16) return 0;
   const int ncls = p->n_cls > 1 ? p->n_cls : 1;
   long M = 0;
   for (int c = 0; c < ncls; ++c) {
-    const long m = ncls > 1 ? (long)p->n_img * p->cls[c].g_H * p->cls[c].g_W : (long)p->n_img * p->g_H * p->g_W;
+    const long m = ncls > 1 ? (long)p->n_img * p->cls[c].g_H * p->cls[c].g_W : (long)p->n_img * p->g_H * p->g_W * (p->g_D > 0 ? p->g_D : 1);
     M = m > M ? m : M;
     const long xc = p->x_C;
-    const long k = (ncls > 1 ? (long)p->cls[c].taps_y * p->cls[c].taps_x : (long)p->taps_y * p->taps_x) * xc;
+    const long k = (ncls > 1 ? (long)p->cls[c].taps_y * p->cls[c].taps_x : (long)p->taps_y * p->taps_x * (p->taps_z > 0 ? p->taps_z : 1)) * xc;
     if (k < 64) return 0;
   }
   const int bn = p->tile_n == 256 ? 256 : (p->tile_n == 128 ? 128 : (p->N > 128 ? 256 : 128));

@@ -162,3 +162,45 @@ def test_wide_backward_weights(case):
         outs[tag] = lay.grad_w.float().cpu()
         assert _rel(outs[tag], ref) < 2e-3, (tag, _rel(outs[tag], ref))        # fp32 accumulation of exact bf16 products: order only
     assert _rel(outs["wide"], outs["ring"]) < 1e-4 and _rel(outs["wide-split3"], outs["ring-split3"]) < 1e-4
+
+
+@pytest.mark.parametrize("case", [(64, 128, 3, 1, 12, 2), (128, 64, 5, 2, 16, 1), (72, 200, 3, 2, 10, 2)])   # cin, cout, k, stride, size, B
+def test_wide_conv3d_forward_and_backward_data(case):
+    """The depth axis of conv_wide.hip (Conv3d forward and backward-data per parity class, reference models.py:39-43 generalised by
+    BASELINE configs[4]) against torch's conv3d on bf16-rounded operands and against the 128-row ring kernel."""
+    from mireg import affine3d
+    from mireg.affine3d import Conv3dLayer, Vol
+    from mireg.engine import Workspace, assign_tiles, upload_table, _stream
+    from mireg import _lib
+    cin, cout, k, s, n, B = case
+    ws = Workspace(torch.device(DEV), torch.bfloat16)
+    g = torch.Generator().manual_seed(cin + cout)
+    pad = (k - 1) // 2
+    x = torch.randn(B, cin, n, n, n, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, k, k, k, generator=g) / (cin * k ** 3) ** 0.5).bfloat16().float()
+    y_ref = F.leaky_relu(F.conv3d(x, w, None, s, pad), 0.1)
+    no = y_ref.shape[-1]
+    cot = torch.randn(B, cout, no, no, no, generator=g).bfloat16().float()
+    dx_ref = F.conv_transpose3d(cot, w, None, s, pad, output_padding=n - ((no - 1) * s - 2 * pad + k))
+    outs = {}
+    try:
+        for tag, force in (("ring", ()), ("wide128", (128,)), ("wide256", (256,))):
+            affine3d.FORCE_WIDE = force
+            lay = Conv3dLayer(w.to(DEV), None, (s, s, s), (pad, pad, pad), ws)
+            jobs = [lay.pack_job()]
+            units, dunits = assign_tiles(jobs, False)
+            tab = upload_table(jobs, DEV)
+            _lib.call("mireg_pack_weights", tab.data_ptr(), 1, units, dunits, ws.code, _stream())
+            mk = lambda t, c, m: Vol(torch.zeros(B, m, m, m, (c + 7) // 8 * 8, device=DEV, dtype=torch.bfloat16), (m, m, m), c)
+            xv, yv, gv, dxv = mk(x, cin, n), mk(None, cout, no), mk(cot, cout, no), mk(None, cin, n)
+            xv.buf[..., :cin] = x.permute(0, 2, 3, 4, 1).to(DEV)
+            gv.buf[..., :cout] = cot.permute(0, 2, 3, 4, 1).to(DEV)
+            lay.run(xv, (n, n, n), yv, 0.1)
+            lay.dgrad(gv, (no, no, no), dxv, (n, n, n))
+            torch.cuda.synchronize()
+            outs[tag] = (yv.buf[..., :cout].permute(0, 4, 1, 2, 3).float().cpu(), dxv.buf[..., :cin].permute(0, 4, 1, 2, 3).float().cpu())
+            assert _rel(outs[tag][0], y_ref) < 3e-2 and _rel(outs[tag][1], dx_ref) < 3e-2, tag
+    finally:
+        affine3d.FORCE_WIDE = None
+    for tag in ("wide128", "wide256"):
+        assert _rel(outs[tag][0], outs["ring"][0]) < 2 ** -7 and _rel(outs[tag][1], outs["ring"][1]) < 2 ** -6, tag
