@@ -111,250 +111,6 @@ def _grad_report(m_hip, m_cpu, m_ref):
 
 
 @pytest.mark.parametrize("which", ["FlowNetSD", "FlowNetFusion", "FlowNet2S"])
-def test_flownet2_subnetworks_fp32_golden(golden, which):
-    import mireg
-    g = golden("g9_flownet2")
-    key, shape, seed, ocls = {"FlowNetSD": ("flownetsd", (2, 2, 64, 64), 21, nets.FlowNetSD),
-                              "FlowNetFusion": ("flownetfusion", (2, 9, 64, 64), 22, nets.FlowNetFusion),
-                              "FlowNet2S": ("flownets", (2, 6, 64, 64), 23, nets.FlowNet2S)}[which]
-    m = getattr(mireg, which)(None, batchNorm=True, precision="fp32")
-    assert list(m.state_dict().keys()) == list(ocls(None, batchNorm=True).state_dict().keys())
-    nets.analytic_weights_(m)
-    m = m.to(DEV)
-    x = nets.analytic_input(shape, seed=seed, lo=-1.0, hi=1.0).to(DEV)
-    for mode in ("train", "eval"):
-        m.train(mode == "train")
-        with torch.no_grad():
-            out = m(x)
-        out = out if isinstance(out, tuple) else (out,)
-        assert len(out) == sum(k.startswith(f"{key}_{mode}_") for k in g.files)
-        # train mode: the deep BatchNorms normalise over 2..32 samples here (64x64 inputs, batch 2), which amplifies fp32
-        # summation-order noise exactly as G1 records for FlowNetS
-        tol = 3e-3 if mode == "train" else 5e-4
-        for i, o in enumerate(out):
-            assert _err(o, g[f"{key}_{mode}_{i}"]) <= tol, (mode, i, _err(o, g[f"{key}_{mode}_{i}"]))
-
-
-def test_flownet2_chain_fp32_golden_and_bf16(golden):
-    import mireg
-    g = golden("g9_flownet2")
-    m = mireg.FlowNet2(None, batchNorm=True, precision="fp32")
-    assert list(m.state_dict().keys()) == list(nets.FlowNet2(None, batchNorm=True).state_dict().keys())
-    nets.analytic_weights_(m)
-    m = m.to(DEV).eval()
-    x = nets.analytic_input((1, 2, 256, 256), seed=24).to(DEV)
-    with torch.no_grad():
-        st = m.stages(x)
-        a, b = m(x)
-    assert a.shape == (1, 2, 256, 256) and torch.equal(a, b)              # flownet2/models.py:189 returns the fused flow twice
-    for name, t in zip(("flownetc_flow2", "flownets1_flow2", "flownets2_flow2", "flownetsd_flow2"), st[:4]):
-        assert _err(t, g[f"flownet2_{name}"]) <= 1e-3, (name, _err(t, g[f"flownet2_{name}"]))
-    assert _err(st[-1][:, :, ::2, ::2], g["flownet2_fused"]) <= 2e-3, _err(st[-1][:, :, ::2, ::2], g["flownet2_fused"])
-    m16 = mireg.FlowNet2(None, batchNorm=True, precision="bf16")
-    m16.load_state_dict(m.state_dict())
-    m16 = m16.to(DEV).eval()
-    with torch.no_grad():
-        f16 = m16(x)[0]
-    rel = ((f16 - a).norm() / a.norm()).item()
-    assert rel < 0.2, rel                                  # measured 0.12 with these random weights
-
-
-def test_registration_wrapper_with_flownet2():
-    """opticalFlowReg('flownet2') (reference models.py:212-225): two identical full-resolution flows, each warped."""
-    import mireg
-    reg = mireg.opticalFlowReg("flownet2", precision="bf16").to(DEV).eval()
-    x = nets.analytic_input((2, 2, 256, 256), seed=5).to(DEV)
-    with torch.no_grad():
-        flows, warped, _, _ = reg(x)
-    assert len(flows) == 2 and len(warped) == 2 and flows[0].shape == (2, 2, 256, 256) and warped[0].shape == (2, 1, 256, 256)
-    assert torch.isfinite(flows[0]).all() and torch.isfinite(warped[0]).all()
-    # the reference's training loop on it (train.py:48-57): forward, OFEloss, backward, Adam(eps=1e-4)
-    reg.train()
-    opt = mireg.Adam(reg.parameters(), 1e-4, eps=1e-4)
-    before = [p.detach().clone() for p in reg.parameters()]
-    flows, warped, _, _ = reg(x)
-    loss = mireg.OFEloss(flows, warped, x[:, 0:1])[3]
-    opt.zero_grad()
-    loss.backward()
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in reg.parameters())
-    opt.step()
-    moved = sum(int(not torch.equal(a, b)) for a, b in zip(before, reg.parameters()))
-    assert moved > 0.9 * len(before) and torch.isfinite(loss)
-
-
-@pytest.mark.parametrize("which", ["FlowNetSD", "FlowNetFusion", "FlowNet2S"])
-def test_flownet2_subnetworks_fp32_golden(golden, which):
-    import mireg
-    g = golden("g9_flownet2")
-    key, shape, seed, ocls = {"FlowNetSD": ("flownetsd", (2, 2, 64, 64), 21, nets.FlowNetSD),
-                              "FlowNetFusion": ("flownetfusion", (2, 9, 64, 64), 22, nets.FlowNetFusion),
-                              "FlowNet2S": ("flownets", (2, 6, 64, 64), 23, nets.FlowNet2S)}[which]
-    m = getattr(mireg, which)(None, batchNorm=True, precision="fp32")
-    assert list(m.state_dict().keys()) == list(ocls(None, batchNorm=True).state_dict().keys())
-    nets.analytic_weights_(m)
-    m = m.to(DEV)
-    x = nets.analytic_input(shape, seed=seed, lo=-1.0, hi=1.0).to(DEV)
-    for mode in ("train", "eval"):
-        m.train(mode == "train")
-        with torch.no_grad():
-            out = m(x)
-        out = out if isinstance(out, tuple) else (out,)
-        assert len(out) == sum(k.startswith(f"{key}_{mode}_") for k in g.files)
-        # train mode: the deep BatchNorms normalise over 2..32 samples here (64x64 inputs, batch 2), which amplifies fp32
-        # summation-order noise exactly as G1 records for FlowNetS (DESIGN.md section 2)
-        tol = 3e-3 if mode == "train" else 5e-4
-        for i, o in enumerate(out):
-            assert _err(o, g[f"{key}_{mode}_{i}"]) <= tol, (mode, i, _err(o, g[f"{key}_{mode}_{i}"]))
-
-
-def test_flownet2_chain_fp32_golden_and_bf16(golden):
-    import mireg
-    g = golden("g9_flownet2")
-    m = mireg.FlowNet2(None, batchNorm=True, precision="fp32")
-    assert list(m.state_dict().keys()) == list(nets.FlowNet2(None, batchNorm=True).state_dict().keys())
-    nets.analytic_weights_(m)
-    m = m.to(DEV).eval()
-    x = nets.analytic_input((1, 2, 256, 256), seed=24).to(DEV)
-    with torch.no_grad():
-        st = m.stages(x)
-        a, b = m(x)
-    assert a.shape == (1, 2, 256, 256) and torch.equal(a, b)              # flownet2/models.py:189 returns the fused flow twice
-    for name, t in zip(("flownetc_flow2", "flownets1_flow2", "flownets2_flow2", "flownetsd_flow2"), st[:4]):
-        assert _err(t, g[f"flownet2_{name}"]) <= 1e-3, (name, _err(t, g[f"flownet2_{name}"]))
-    assert _err(st[-1][:, :, ::2, ::2], g["flownet2_fused"]) <= 2e-3, _err(st[-1][:, :, ::2, ::2], g["flownet2_fused"])
-    m16 = mireg.FlowNet2(None, batchNorm=True, precision="bf16")
-    m16.load_state_dict(m.state_dict())
-    m16 = m16.to(DEV).eval()
-    with torch.no_grad():
-        f16 = m16(x)[0]
-    rel = ((f16 - a).norm() / a.norm()).item()
-    assert rel < 0.2, rel                                  # measured 0.12 with these random weights
-
-
-def test_registration_wrapper_with_flownet2():
-    """opticalFlowReg('flownet2') (reference models.py:212-225): two identical full-resolution flows, each warped."""
-    import mireg
-    reg = mireg.opticalFlowReg("flownet2", precision="bf16").to(DEV).eval()
-    x = nets.analytic_input((2, 2, 256, 256), seed=5).to(DEV)
-    with torch.no_grad():
-        flows, warped, _, _ = reg(x)
-    assert len(flows) == 2 and len(warped) == 2 and flows[0].shape == (2, 2, 256, 256) and warped[0].shape == (2, 1, 256, 256)
-    assert torch.isfinite(flows[0]).all() and torch.isfinite(warped[0]).all()
-    # the reference's training loop on it (train.py:48-57): forward, OFEloss, backward, Adam(eps=1e-4)
-    reg.train()
-    opt = mireg.Adam(reg.parameters(), 1e-4, eps=1e-4)
-    before = [p.detach().clone() for p in reg.parameters()]
-    flows, warped, _, _ = reg(x)
-    loss = mireg.OFEloss(flows, warped, x[:, 0:1])[3]
-    opt.zero_grad()
-    loss.backward()
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in reg.parameters())
-    opt.step()
-    moved = sum(int(not torch.equal(a, b)) for a, b in zip(before, reg.parameters()))
-    assert moved > 0.9 * len(before) and torch.isfinite(loss)
-
-
-def _grad_report(m_hip, m_cpu, m_ref):
-    """Against m_ref (the oracle run in float64): relative L2 over all parameter gradients together and the worst per-parameter
-    relative L2 among the gradients that carry at least 1e-3 of the total norm, for the HIP model and for the fp32 oracle itself
-    (= the fp32 noise of this computation: LeakyReLU kink flips, few-sample BatchNorms)."""
-    gr = {k: p.grad.detach().double().flatten() for k, p in m_ref.named_parameters()}
-    out = []
-    for mod in (m_hip, m_cpu):
-        g = {k: p.grad.detach().double().cpu().flatten() for k, p in mod.named_parameters()}
-        assert set(g) == set(gr)
-        tot = torch.cat([gr[k] for k in gr]).norm().item()
-        err = torch.cat([g[k] - gr[k] for k in gr]).norm().item()
-        worst = max(((g[k] - gr[k]).norm() / gr[k].norm()).item() for k in gr if gr[k].norm().item() > 1e-3 * tot)
-        out.append((err / tot, worst))
-    return out
-
-
-@pytest.mark.parametrize("which", ["FlowNetSD", "FlowNetFusion", "FlowNet2S"])
-def test_flownet2_subnetworks_fp32_golden(golden, which):
-    import mireg
-    g = golden("g9_flownet2")
-    key, shape, seed, ocls = {"FlowNetSD": ("flownetsd", (2, 2, 64, 64), 21, nets.FlowNetSD),
-                              "FlowNetFusion": ("flownetfusion", (2, 9, 64, 64), 22, nets.FlowNetFusion),
-                              "FlowNet2S": ("flownets", (2, 6, 64, 64), 23, nets.FlowNet2S)}[which]
-    m = getattr(mireg, which)(None, batchNorm=True, precision="fp32")
-    assert list(m.state_dict().keys()) == list(ocls(None, batchNorm=True).state_dict().keys())
-    nets.analytic_weights_(m)
-    m = m.to(DEV)
-    x = nets.analytic_input(shape, seed=seed, lo=-1.0, hi=1.0).to(DEV)
-    for mode in ("train", "eval"):
-        m.train(mode == "train")
-        with torch.no_grad():
-            out = m(x)
-        out = out if isinstance(out, tuple) else (out,)
-        assert len(out) == sum(k.startswith(f"{key}_{mode}_") for k in g.files)
-        # train mode: the deep BatchNorms normalise over 2..32 samples here (64x64 inputs, batch 2), which amplifies fp32
-        # summation-order noise exactly as G1 records for FlowNetS (DESIGN.md section 2)
-        tol = 3e-3 if mode == "train" else 5e-4
-        for i, o in enumerate(out):
-            assert _err(o, g[f"{key}_{mode}_{i}"]) <= tol, (mode, i, _err(o, g[f"{key}_{mode}_{i}"]))
-
-
-def test_flownet2_chain_fp32_golden_and_bf16(golden):
-    import mireg
-    g = golden("g9_flownet2")
-    m = mireg.FlowNet2(None, batchNorm=True, precision="fp32")
-    assert list(m.state_dict().keys()) == list(nets.FlowNet2(None, batchNorm=True).state_dict().keys())
-    nets.analytic_weights_(m)
-    m = m.to(DEV).eval()
-    x = nets.analytic_input((1, 2, 256, 256), seed=24).to(DEV)
-    with torch.no_grad():
-        st = m.stages(x)
-        a, b = m(x)
-    assert a.shape == (1, 2, 256, 256) and torch.equal(a, b)              # flownet2/models.py:189 returns the fused flow twice
-    for name, t in zip(("flownetc_flow2", "flownets1_flow2", "flownets2_flow2", "flownetsd_flow2"), st[:4]):
-        assert _err(t, g[f"flownet2_{name}"]) <= 1e-3, (name, _err(t, g[f"flownet2_{name}"]))
-    assert _err(st[-1][:, :, ::2, ::2], g["flownet2_fused"]) <= 2e-3, _err(st[-1][:, :, ::2, ::2], g["flownet2_fused"])
-    m16 = mireg.FlowNet2(None, batchNorm=True, precision="bf16")
-    m16.load_state_dict(m.state_dict())
-    m16 = m16.to(DEV).eval()
-    with torch.no_grad():
-        f16 = m16(x)[0]
-    rel = ((f16 - a).norm() / a.norm()).item()
-    assert rel < 0.2, rel                                  # measured 0.12 with these random weights
-
-
-def test_registration_wrapper_with_flownet2():
-    """opticalFlowReg('flownet2') (reference models.py:212-225): two identical full-resolution flows, each warped."""
-    import mireg
-    reg = mireg.opticalFlowReg("flownet2", precision="bf16").to(DEV).eval()
-    x = nets.analytic_input((2, 2, 256, 256), seed=5).to(DEV)
-    with torch.no_grad():
-        flows, warped, _, _ = reg(x)
-    assert len(flows) == 2 and len(warped) == 2 and flows[0].shape == (2, 2, 256, 256) and warped[0].shape == (2, 1, 256, 256)
-    assert torch.isfinite(flows[0]).all() and torch.isfinite(warped[0]).all()
-    # the reference's training loop on it (train.py:48-57): forward, OFEloss, backward, Adam(eps=1e-4)
-    reg.train()
-    opt = mireg.Adam(reg.parameters(), 1e-4, eps=1e-4)
-    before = [p.detach().clone() for p in reg.parameters()]
-    flows, warped, _, _ = reg(x)
-    loss = mireg.OFEloss(flows, warped, x[:, 0:1])[3]
-    opt.zero_grad()
-    loss.backward()
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in reg.parameters())
-    opt.step()
-    moved = sum(int(not torch.equal(a, b)) for a, b in zip(before, reg.parameters()))
-    assert moved > 0.9 * len(before) and torch.isfinite(loss)
-
-
-def _grad_report(m_hip, m_cpu):
-    """(relative L2 over all parameter gradients together, worst per-parameter relative L2 among the gradients that carry
-    at least 1e-3 of the total norm)."""
-    gh = {k: p.grad.detach().double().cpu().flatten() for k, p in m_hip.named_parameters()}
-    gc = {k: p.grad.detach().double().flatten() for k, p in m_cpu.named_parameters()}
-    assert set(gh) == set(gc)
-    tot = torch.cat([gc[k] for k in gc]).norm().item()
-    err = torch.cat([gh[k] - gc[k] for k in gc]).norm().item()
-    worst = max(((gh[k] - gc[k]).norm() / gc[k].norm()).item() for k in gc if gc[k].norm().item() > 1e-3 * tot)
-    return err / tot, worst
-
-
-@pytest.mark.parametrize("which", ["FlowNetSD", "FlowNetFusion", "FlowNet2S"])
 def test_flownet2_subnetworks_backward_vs_cpu_autograd(which):
     """HIP backward of the stack's sub-networks (every parameter gradient, and the input gradient where the chain needs one)
     against torch autograd through the CPU restatement, fp32, train-mode BatchNorm.  Bounds as for FlowNetS (G1): LeakyReLU
