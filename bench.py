@@ -454,6 +454,24 @@ def main():
                                             "batch": 8, "note": "configs[4]: FlowNetS over 128^3 volume pairs (Conv3d / BatchNorm3d / "
                                             "ConvTranspose3d, 3-channel flow), six-scale warp + OFEloss3d, HIP backward, Adam; eager, 1 GPU"}
             log(f"3-D FlowNetS train: {8 / t3:.2f} volumes/s ({t3 * 1e3:.1f} ms/step)")
+            # the same step replayed from one hipGraph (capturable since round 3: job tables are cached, gradient buffers persistent)
+            try:
+                import gc
+                gr3, s3 = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+                s3.wait_stream(torch.cuda.current_stream())
+                gc.disable()
+                try:
+                    with torch.cuda.stream(s3):
+                        with torch.cuda.graph(gr3, stream=s3):
+                            f3_train()
+                finally:
+                    gc.enable()
+                tg, _ = timed(gr3.replay, 5, warm=1)
+                vol_line["flownets3d_train"]["hipgraph"] = {"ms_per_step": round(tg * 1e3, 3), "volumes_per_s": round(8 / tg, 1)}
+                log(f"3-D FlowNetS train, hipGraph replay: {tg * 1e3:.1f} ms/step")
+                del gr3
+            except Exception as e:                                   # noqa: BLE001
+                vol_line["flownets3d_train"]["hipgraph"] = {"error": repr(e)}
             # quality on a genuine synthetic pair: moving = the fixed volume pushed through a smooth random displacement field
             # (on device), 4-label masks from intensity thresholds; warped-Dice after a short run from random init
             try:

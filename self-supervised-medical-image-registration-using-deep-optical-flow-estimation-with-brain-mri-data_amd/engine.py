@@ -149,11 +149,27 @@ def run_unpack(jobs: Sequence["PackJob"], device) -> None:
     _lib.call("mireg_unpack_wgrad", tab.data_ptr(), len(jobs), units, _stream())
 
 
+_TABLE_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
 def upload_table(jobs: Sequence[ctypes.Structure], device) -> torch.Tensor:
-    """Copy an array of POD job structs into a device byte tensor (kept alive by the caller)."""
+    """An array of POD job structs as a device byte tensor.  Tables are cached by content (they are read-only for the kernels and a
+    step rebuilds the same ones over persistent buffers): the steady state issues no host-to-device copy, which is also what lets a
+    whole step be captured into a hipGraph -- a pageable upload is not capturable, and that, not a fault in a kernel, is what stopped
+    the 3-D step's capture in round 2 (scratch/capture3d.py)."""
     arr = (type(jobs[0]) * len(jobs))(*jobs)
     raw = bytes(memoryview(arr).cast("B"))
-    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else -1, type(jobs[0]).__name__, raw)
+    tab = _TABLE_CACHE.get(key)
+    if tab is None:
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mireg: a new job table would have to be uploaded inside a hipGraph capture; run the step eagerly once "
+                               "before capturing so that its tables exist (buffers must be persistent)")
+        if len(_TABLE_CACHE) >= 8192:
+            _TABLE_CACHE.clear()
+        tab = _TABLE_CACHE[key] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    return tab
 
 
 @dataclass

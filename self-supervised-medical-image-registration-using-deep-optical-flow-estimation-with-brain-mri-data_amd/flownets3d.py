@@ -238,6 +238,17 @@ class FlowNetS3D(nn.Module):
                 lay.dgrad(e["graw"][name], odims, gact[prev[name]], src.dims, accumulate=prev[name] in ("conv2", "conv3_1", "conv4_1", "conv5_1"))
         # ---- gradients in named_parameters() order ----
         grads, pairs = [], []
+        gbuf = e.setdefault("gbuf", {})                       # persistent gradient buffers: stable pointers = cached job tables, capturable
+
+        def gb(key, like, param=None):
+            """Two buffers per gradient: autograd ADDS a returned gradient onto an existing .grad, so the buffer handed back must never
+            be the tensor .grad currently aliases (it adopts the returned tensor when .grad was None)."""
+            pair = gbuf.setdefault(key, [None, None])
+            i = 1 if (param is not None and param.grad is not None and pair[0] is not None
+                      and param.grad.data_ptr() == pair[0].data_ptr()) else 0
+            if pair[i] is None:
+                pair[i] = torch.empty_like(like, dtype=torch.float32)
+            return pair[i]
         conv_of = {}
         for name, _, _ in ENC:
             conv_of[f"{name}.0.weight"] = L[name]
@@ -248,20 +259,23 @@ class FlowNetS3D(nn.Module):
             conv_of[f"upsampled_flow{lv + 1}_to_{lv}.weight"] = L[f"up{lv}"]
         for pname, p in self._named():
             if pname == "conv1.0.weight":
-                g = e["g1s"] = torch.empty_like(e["w1s"])                             # gradient in the stem layout, mapped back below
+                g = e["g1s"] = gb("g1s", e["w1s"])                                    # gradient in the stem layout, mapped back below
                 pairs.append((conv_of[pname], g))
             elif pname in conv_of:
-                g = torch.empty_like(p, dtype=torch.float32)          # every element is written by the unpack
+                g = gb(pname, p, p)                                    # every element is written by the unpack
                 pairs.append((conv_of[pname], g))
             else:                                                                    # BatchNorm3d weight / bias
                 lname, _, kind = pname.split(".")
-                g = (e["bns"][lname].grad_g if kind == "weight" else e["bns"][lname].grad_b).clone()
+                g = gb(pname, p, p)
+                g.copy_(e["bns"][lname].grad_g if kind == "weight" else e["bns"][lname].grad_b)
             grads.append(g)
         e["_tab"] = Conv3dLayer.unpack_grads(pairs, ws)
         names = [n for n, _ in self._named()]
         c1 = e["g1s"].shape[0]                                                        # [co][tx*2 + ci][tz][ty][1] -> [co][ci][tz][ty][tx]
-        grads[names.index("conv1.0.weight")] = e["g1s"][:, :14, :, :, 0].reshape(c1, 7, 2, 7, 7).permute(0, 2, 3, 4, 1).contiguous()
-        return [g.to(p.dtype) for g, (_, p) in zip(grads, self._named())]
+        g1 = gb("conv1.0.weight", self.conv1[0].weight, self.conv1[0].weight)
+        g1.copy_(e["g1s"][:, :14, :, :, 0].reshape(c1, 7, 2, 7, 7).permute(0, 2, 3, 4, 1))
+        grads[names.index("conv1.0.weight")] = g1
+        return grads
 
 
 class opticalFlowReg3d(nn.Module):

@@ -288,3 +288,49 @@ def test_flownets3d_warped_segmentation_dice_vs_oracle():
     dice = mireg.dice_batch(segs[:, 0:1].to(DEV), wseg)
     for b in range(2):
         assert abs(dice[b].item() - float(oops.dice_average(segs[b, 0], wseg_ref[b, 0]))) < 2e-3
+
+
+def test_flownets3d_train_step_captures_into_a_hipgraph_and_replays_like_eager():
+    """The whole 3-D training step (forward, six-scale warp, OFEloss3d, HIP backward through autograd, mireg.Adam) is capturable once
+    its job tables exist (round 2 recorded a crash here: the per-step pageable table uploads, scratch/capture3d.py): two eager
+    steps, capture the third, replay two more; an eager-only twin fed the same batch ends with the same parameters."""
+    import gc
+    import mireg
+    torch.manual_seed(3)
+    x = torch.rand(2, 2, 64, 64, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def build():
+        torch.manual_seed(5)
+        m = mireg.opticalFlowReg3d(precision="bf16", width_div=8).to(DEV).train()
+        return m, mireg.Adam(m.parameters(), 1e-4, eps=1e-4)
+
+    def step(m, opt):
+        flows, warped = m(x)
+        loss = mireg.OFEloss3d(flows, warped, x[:, 0:1])[3]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    ma, oa = build()
+    for _ in range(5):
+        step(ma, oa)
+    mb, ob = build()
+    for _ in range(2):
+        step(mb, ob)
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        gr, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(gr, stream=s):
+                step(mb, ob)
+    finally:
+        gc.enable()
+    for _ in range(3):                                         # the capture itself does not execute: three replays = steps 3, 4, 5
+        gr.replay()
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.isfinite(b).all()
+        assert (a - b).abs().max().item() <= 1e-5 + 1e-4 * a.abs().max().item(), k
