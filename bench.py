@@ -438,7 +438,7 @@ def main():
                 opt_f.zero_grad()
                 loss.backward()
                 opt_f.step()
-                return loss
+                return loss.detach()      # a live loss keeps last step's AccumulateGrad nodes (and their stream) alive, which breaks capture
             t3, l3 = timed(f3_train, 3, warm=1)
             PROFILER.enabled, PROFILER.records, PROFILER.byte_records = True, [], []
             f3_train()

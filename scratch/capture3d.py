@@ -35,10 +35,34 @@ try:
         with torch.cuda.graph(gr, stream=s):
             loss = step()
     print("capture OK", flush=True)
-    for _ in range(3):
-        gr.replay()
+    gr.replay()
     torch.cuda.synchronize()
-    print("replayed 3 times, loss", float(loss), flush=True)
+    print("first replay: loss", float(loss), flush=True)
+    e = list(reg3.predictor._eng.values())[0]
+    def chk(tag, t):
+        t = t.float()
+        n = int((~torch.isfinite(t)).sum())
+        if n:
+            print(f"   non-finite: {tag}: {n} of {t.numel()}", flush=True)
+    for grp in ("raw", "act", "flow32", "gflow", "gcat", "graw", "gact"):
+        for k, v in e[grp].items():
+            chk(f"{grp}[{k}]", v.buf)
+    for k, l in e["layers"].items():
+        if getattr(l, "slab", None) is not None:
+            chk(f"slab[{k}]", l.slab)
+    for k, pair in e.get("gbuf", {}).items():
+        for i, t in enumerate(pair):
+            if t is not None:
+                chk(f"gbuf[{k}][{i}]", t)
+    for k, p_ in reg3.named_parameters():
+        if p_.grad is not None:
+            chk(f"grad {k}", p_.grad)
+        chk(f"param {k}", p_)
+    print("checked", flush=True)
+    for i in range(3):
+        gr.replay(); torch.cuda.synchronize()
+        bad = [k for k, p in reg3.named_parameters() if not torch.isfinite(p).all()]
+        print("replay", i, "loss", float(loss), "non-finite parameters:", bad[:4], flush=True)
 except BaseException as e:                                    # noqa: BLE001
     print("capture failed with", type(e).__name__, ":", str(e)[:600], flush=True)
     traceback.print_exc()

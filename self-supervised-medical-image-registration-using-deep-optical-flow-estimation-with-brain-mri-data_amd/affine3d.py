@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import _lib
 from . import engine as engine_mod
 from .engine import DT_BF16, PROFILER, ConvDesc, Pack3dJob, PackJob, View, WoptJob, Workspace, _stream, assign_tiles, rup, upload_table
-from .ops import SLOTS
+from .ops import SLOTS, pixel_counts
 
 SPEC = [(2, 16, 7, (2, 2, 1)), (16, 32, 5, (2, 2, 1)), (32, 64, 3, (2, 2, 2)), (64, 128, 3, (2, 2, 2)),
         (128, 256, 3, (2, 2, 2)), (256, 512, 3, (2, 2, 2))]
@@ -437,7 +437,7 @@ class _AfflossFn(torch.autograd.Function):
         w, f = warped.detach().float().contiguous(), fixed.detach().float().contiguous()
         B, n = w.shape[0], w.numel()
         sums = torch.zeros(1, SLOTS, 8, device=w.device, dtype=torch.float64)
-        npix = torch.tensor([n], dtype=torch.int64, device=w.device)
+        npix = pixel_counts([n], w.device)
         out = torch.empty(4, device=w.device, dtype=torch.float64)
         st = _stream()
         _lib.call("mireg_loss_partials", w.data_ptr(), f.data_ptr(), sums.data_ptr(), n, st)

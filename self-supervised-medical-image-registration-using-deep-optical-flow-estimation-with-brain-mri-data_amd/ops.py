@@ -16,6 +16,21 @@ F32 = torch.float32
 SLOTS = 32          # MIREG_SUM_SLOTS: replicas of every moment row (include/mireg.h)
 
 
+_COUNTS = {}
+
+
+def pixel_counts(values, dev: torch.device) -> torch.Tensor:
+    """int64 device vector of per-scale element counts, uploaded once per (device, values): a pageable host-to-device copy
+    inside a hipGraph capture records the host pointer, which is gone by the time the graph replays."""
+    key = (dev.type, dev.index, tuple(int(v) for v in values))
+    t = _COUNTS.get(key)
+    if t is None:
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mireg: a new pixel-count table would be uploaded inside a hipGraph capture; run the step once eagerly first")
+        t = _COUNTS[key] = torch.tensor(key[2], dtype=torch.int64, device=dev)
+    return t
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -116,7 +131,7 @@ class _OFELossFn(torch.autograd.Function):
         dev = fixed.device
         B = fixed.shape[0]
         sums = torch.zeros(n, SLOTS, 8, device=dev, dtype=torch.float64)
-        npix = torch.tensor([w.numel() for w in warped], dtype=torch.int64).to(dev, non_blocking=True)
+        npix = pixel_counts([w.numel() for w in warped], dev)
         fixed_rs, wcs, fviews = [], [], []
         st = _stream()
         for i in range(n):

@@ -34,7 +34,10 @@ class Adam:
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self._tab = None
 
-    def zero_grad(self, set_to_none: bool = True) -> None:
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        """Default: keep the gradient tensors and zero them (one fill per tensor).  torch.optim's default drops them instead; with
+        stable gradient storage the per-step job table of step() never changes (no host-to-device copy after the first step) and the
+        whole training step can be captured into a hipGraph.  Pass set_to_none=True for torch's behaviour."""
         for p in self.params:
             if p.grad is not None:
                 if set_to_none:

@@ -10,7 +10,7 @@ from typing import Sequence, Tuple
 import torch
 
 from . import _lib
-from .ops import SLOTS, _need_gpu, _stream
+from .ops import SLOTS, _need_gpu, _stream, pixel_counts
 
 F32 = torch.float32
 
@@ -99,7 +99,7 @@ class _OFELoss3dFn(torch.autograd.Function):
         _need_gpu(fixed, *flows, *warped)
         dev, B, st = fixed.device, fixed.shape[0], _stream()
         sums = torch.zeros(n, SLOTS, 8, device=dev, dtype=torch.float64)
-        npix = torch.tensor([w.numel() for w in warped], dtype=torch.int64).to(dev, non_blocking=True)
+        npix = pixel_counts([w.numel() for w in warped], dev)
         fixed_rs, wcs, fviews = [], [], []
         for i in range(n):
             wi = warped[i].contiguous()
