@@ -430,7 +430,7 @@ def main():
             torch.cuda.empty_cache()
             # BASELINE configs[4]: FlowNetS over 128^3 volumes, batch 8 -- full widths, train step
             reg3 = mireg.opticalFlowReg3d(precision=args.precision).to(dev).train()
-            opt_f = mireg.Adam(reg3.parameters(), 1e-4, eps=1e-4)
+            opt_f = mireg.Adam(reg3.parameters(), 1e-4, eps=1e-4, fuse=reg3)       # convolution weights: packed-domain Adam (mireg_adam_pack)
 
             def f3_train():
                 flows, warped = reg3(vol)

@@ -390,7 +390,7 @@ typedef struct mireg_wopt_job {
   int unit0;      /* first optimizer block: blocks = Co * ceil(Cpad/64) */
 } mireg_wopt_job;
 int mireg_wgrad_reduce(const mireg_wopt_job* jobs_dev, int njobs, int total_runits, hipStream_t stream);
-/* max_taps = largest kh*kw in the table (<= 49); tick != 0 increments *step_dev first (as mireg_adam_step does) */
+/* max_taps = largest kd*kh*kw in the table (<= 125: sizes the kernel's LDS tile); tick != 0 increments *step_dev first (as mireg_adam_step does) */
 int mireg_adam_pack(const mireg_wopt_job* jobs_dev, int njobs, int total_units, int max_taps, int* step_dev, int tick,
                     float lr, float beta1, float beta2, float eps, float grad_scale, int dtype, hipStream_t stream);
 

@@ -729,13 +729,13 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const mireg_wopt_job*
   }
 }
 
-constexpr int kOptMaxTaps = 49;
+constexpr int kOptMaxTaps = 125;     // 5 x 5 x 5 (Conv3d); the LDS tile is sized by the launch's largest tap count
 // block = one (co, 64-ci chunk): packed gradient -> LDS (transposed) -> coalesced torch-order Adam -> FWD pack row
 template <typename T>
 __global__ void __launch_bounds__(256)
 adam_pack_kernel(const mireg_wopt_job* __restrict__ jobs, int njobs, const int* __restrict__ step, float lr, float b1, float b2,
                  float eps, float grad_scale) {
-  __shared__ float tile[64 * kOptMaxTaps];
+  extern __shared__ float opt_tile[];                                  // 64 * (max_taps | 1) floats
   const mireg_wopt_job j = jobs[find_wopt(jobs, njobs, blockIdx.x, false)];
   const int taps = j.taps, tp = taps | 1, tid = threadIdx.x;
   const int chunks = (j.Cpad + 63) / 64;
@@ -749,25 +749,25 @@ adam_pack_kernel(const mireg_wopt_job* __restrict__ jobs, int njobs, const int* 
   const float* g = j.g + (long)co * j.ld + ci0;
   for (int e = tid; e < taps * 64; e += 256) {
     const int tap = e >> 6, ci = e & 63;
-    if (ci < nci) tile[ci * tp + tap] = ldf(g + (long)tap * j.Cpad + ci);
+    if (ci < nci) opt_tile[ci * tp + tap] = ldf(g + (long)tap * j.Cpad + ci);
   }
   __syncthreads();
   const unsigned magic = (unsigned)((0x100000000ull + taps - 1) / taps);
   const long base = ((long)co * j.Ci + ci0) * taps;
   for (int r = tid; r < run; r += 256) {
     const int ci = (int)__umulhi((unsigned)r, magic), idx = ci * tp + (r - ci * taps);
-    const float gg = tile[idx] * grad_scale;
+    const float gg = opt_tile[idx] * grad_scale;
     const float m = b1 * ldf(j.m + base + r) + (1.f - b1) * gg;
     const float v = b2 * ldf(j.v + base + r) + (1.f - b2) * gg * gg;
     const float pn = ldf(j.p + base + r) - step_size * (m / (sqrtf(v) / bc2s + eps));
     stf(j.m + base + r, m); stf(j.v + base + r, v); stf(j.p + base + r, pn);
-    tile[idx] = pn;
+    opt_tile[idx] = pn;
   }
   __syncthreads();
   T* F = reinterpret_cast<T*>(j.F) + (long)co * j.ld + ci0;
   for (int e = tid; e < taps * 64; e += 256) {
     const int tap = e >> 6, ci = e & 63;
-    if (ci0 + ci < j.Cpad) stf(F + (long)tap * j.Cpad + ci, ci < nci ? tile[ci * tp + tap] : 0.f);
+    if (ci0 + ci < j.Cpad) stf(F + (long)tap * j.Cpad + ci, ci < nci ? opt_tile[ci * tp + tap] : 0.f);
   }
 }
 
@@ -853,10 +853,11 @@ int mireg_adam_pack(const mireg_wopt_job* jobs_dev, int njobs, int total_units, 
   MIREG_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 256 && total_units > 0 && step_dev && max_taps > 0 && max_taps <= kOptMaxTaps &&
                   (dtype == MIREG_DTYPE_F32 || dtype == MIREG_DTYPE_BF16));
   if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, step_dev);
+  const size_t lds = (size_t)64 * (max_taps | 1) * sizeof(float);
   if (dtype == MIREG_DTYPE_BF16)
-    hipLaunchKernelGGL((adam_pack_kernel<__bf16>), dim3(total_units), dim3(256), 0, stream, jobs_dev, njobs, step_dev, lr, beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL((adam_pack_kernel<__bf16>), dim3(total_units), dim3(256), lds, stream, jobs_dev, njobs, step_dev, lr, beta1, beta2, eps, grad_scale);
   else
-    hipLaunchKernelGGL((adam_pack_kernel<float>), dim3(total_units), dim3(256), 0, stream, jobs_dev, njobs, step_dev, lr, beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL((adam_pack_kernel<float>), dim3(total_units), dim3(256), lds, stream, jobs_dev, njobs, step_dev, lr, beta1, beta2, eps, grad_scale);
   MIREG_LAUNCH_RET();
 }
 

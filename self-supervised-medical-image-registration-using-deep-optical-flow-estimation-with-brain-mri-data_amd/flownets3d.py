@@ -9,6 +9,7 @@ Training goes through torch.autograd: the predictor is one autograd function who
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -16,8 +17,10 @@ import torch.nn as nn
 
 from . import _lib
 from .affine3d import Conv3dLayer, Vol
-from .engine import BatchNormAct, Workspace, _stream, assign_tiles, rup, upload_table, zero_tensors
+from .engine import BatchNormAct, WoptJob, Workspace, _stream, assign_tiles, rup, upload_table, zero_tensors
 from .volume import resize_trilinear, stn3d
+
+WGRAD_SIDE_STREAM = os.environ.get("MIREG_3D_WGRAD_MAIN", "0") != "1"
 
 ENC = [("conv1", 7, 2), ("conv2", 5, 2), ("conv3", 5, 2), ("conv3_1", 3, 1), ("conv4", 3, 2), ("conv4_1", 3, 1),
        ("conv5", 3, 2), ("conv5_1", 3, 1), ("conv6", 3, 2), ("conv6_1", 3, 1)]
@@ -74,6 +77,7 @@ class FlowNetS3D(nn.Module):
                 nn.init.constant_(m.bias, 0)
         self._eng: Dict[tuple, dict] = {}
         self._last = None
+        self._fopt, self._fidx, self._fe = None, {}, None             # packed-domain optimizer (mireg.Adam(fuse=...))
 
     # ---- engine -----------------------------------------------------------------------------------------------------
     def _engine(self, x: torch.Tensor) -> dict:
@@ -134,6 +138,60 @@ class FlowNetS3D(nn.Module):
     def _named(self) -> List[Tuple[str, nn.Parameter]]:
         return list(self.named_parameters())
 
+    @staticmethod
+    def _conv_of(L: dict) -> dict:
+        """parameter name -> engine layer of every convolution weight."""
+        conv_of = {f"{name}.0.weight": L[name] for name, _, _ in ENC}
+        for lv in (6, 5, 4, 3, 2):
+            conv_of[f"predict_flow{lv}.weight"] = L[f"predict_flow{lv}"]
+        for lv in (5, 4, 3, 2):
+            conv_of[f"deconv{lv}.0.weight"] = L[f"deconv{lv}"]
+            conv_of[f"upsampled_flow{lv + 1}_to_{lv}.weight"] = L[f"up{lv}"]
+        return conv_of
+
+    # ---- packed-domain optimizer hook (mireg.Adam(fuse=module)) ---------------------------------------------------------
+    def fuse_optimizer(self, opt, index: Dict[int, int]) -> None:
+        """Every convolution weight but conv1's (whose engine layout is the x-axis im2col of the stem) is updated by `mireg_adam_pack`
+        straight from its backward-weights slab; `index` maps id(parameter) to the optimizer's parameter number."""
+        self._fopt = opt
+        self._fidx = {n: index[id(p)] for n, p in self._named()
+                      if p.dim() == 5 and n != "conv1.0.weight" and id(p) in index}
+
+    def fused_pending(self) -> bool:
+        return self._fe is not None and bool(self._fe.get("slab_pending"))
+
+    def fused_step(self, opt, tick: int) -> None:
+        e = self._fe
+        L, ws, st = e["layers"], e["ws"], _stream()
+        conv_of, params = self._conv_of(L), dict(self._named())
+        red, jobs, r, units, max_taps = [], [], 0, 0, 1
+        for pname, i in self._fidx.items():
+            lay = conv_of[pname]
+            taps = lay.kd * lay.kh * lay.kw
+            j = WoptJob()
+            j.slab = j.g = lay.slab.data_ptr()
+            j.slab_stride, j.nsplit = lay.Co * lay.Kf, lay.slab.shape[0]
+            j.Co, j.Ci, j.taps, j.Cpad, j.ld = lay.Co, lay.Ci, taps, lay.Cip, lay.Kf
+            j.p, j.F = params[pname].data_ptr(), lay.packF.data_ptr()
+            j.m, j.v = opt.state_ptrs(i)
+            j.unit0, j.runit0 = units, r
+            units += lay.Co * ((lay.Cip + 63) // 64)
+            max_taps = max(max_taps, taps)
+            jobs.append(j)
+            if lay.slab.shape[0] > 1:                                                # split-K slabs: summed in place first (fixed order)
+                k = WoptJob.from_buffer_copy(j)
+                red.append(k)
+                r += (lay.Co * lay.Kf + 255) // 256
+        if red:
+            e["_ftab_r"] = upload_table(red, ws.device)
+            _lib.call("mireg_wgrad_reduce", e["_ftab_r"].data_ptr(), len(red), r, st)
+        e["_ftab"] = upload_table(jobs, ws.device)
+        _lib.call("mireg_adam_pack", e["_ftab"].data_ptr(), len(jobs), units, max_taps, opt.step_dev.data_ptr(), int(tick), opt.lr,
+                  opt.betas[0], opt.betas[1], opt.eps, 1.0, ws.code, st)
+        e["slab_pending"] = False
+        # the forward packs now hold the new weights: valid for the next forward unless someone writes the parameters in between
+        e["fresh"] = [(params[n], params[n]._version) for n in self._fidx]
+
     def forward(self, x: torch.Tensor):
         """Training: (flow0, flow2, flow3, flow4, flow5, flow6); eval: (flow0, flow2) -- FlowNetS/FlowNetS.py:83-88 with the
         full-resolution flow0 = trilinear upsample of flow2 (align_corners=False)."""
@@ -153,7 +211,10 @@ class FlowNetS3D(nn.Module):
         x = x.detach().float().contiguous()
         w1 = self.conv1[0].weight.detach()                                          # [co][ci][tz][ty][tx] -> [co][tx*2 + ci][tz][ty][1]
         e["w1s"][:, :14] = w1.permute(0, 4, 1, 2, 3).reshape(w1.shape[0], 14, 7, 7, 1)
-        jobs = [l.pack_job() for l in L.values()]
+        fresh = e.pop("fresh", None)                                                 # set by fused_step: forward packs already rewritten
+        fresh = fresh is not None and all(p._version == v for p, v in fresh)
+        fused_layers = {id(l) for n, l in self._conv_of(L).items() if n in self._fidx} if fresh else set()
+        jobs = [l.pack_job() for l in L.values() if id(l) not in fused_layers]
         units, dunits = assign_tiles(jobs, False)
         tab = upload_table(jobs, x.device)
         _lib.call("mireg_pack_weights", tab.data_ptr(), len(jobs), units, dunits, ws.code, st)
@@ -203,12 +264,28 @@ class FlowNetS3D(nn.Module):
         def mask(g: Vol, a: Vol, slope: float) -> None:
             _lib.call("mireg_lrelu_bwd", g.ptr, g.ld, a.ptr, a.ld, g.rows, g.C, slope, ws.code, st)
 
+        # backward-weights launches go to a second stream (their inputs are final once the main chain reaches them, nothing on the main
+        # chain reads their slabs before the join below): they fill the CUs the backward-data chain leaves idle on the coarse levels
+        main = torch.cuda.current_stream()
+        use_side = WGRAD_SIDE_STREAM and not torch.cuda.is_current_stream_capturing()   # measured: as a graph branch it costs 0.3 ms
+        side = e.get("side") if use_side else None
+        if use_side and side is None:
+            side = e["side"] = torch.cuda.Stream(device=dev)
+
+        def wgrad(lay, *args) -> None:
+            if side is None:
+                lay.wgrad(*args)
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                lay.wgrad(*args)
+
         # ---- decoder, fine to coarse ----
         for lv in (2, 3, 4, 5, 6):
             feat = cat[lv] if lv < 6 else act["conv6_1"]
             gfeat = gcat[lv] if lv < 6 else gact["conv6_1"]
             pf = L[f"predict_flow{lv}"]
-            pf.wgrad(feat, dims[lv], e["gflow"][lv], dims[lv])
+            wgrad(pf, feat, dims[lv], e["gflow"][lv], dims[lv])
             pf.dgrad(e["gflow"][lv], dims[lv], gfeat, dims[lv], accumulate=(lv > 2))   # level 2 opens gcat2, deeper levels add
             if lv == 6:
                 break
@@ -220,11 +297,11 @@ class FlowNetS3D(nn.Module):
             gbelow = gcat[lv + 1] if lv + 1 < 6 else gact["conv6_1"]
             # flow upsampler (ConvTranspose3d 3 -> 3): d/d flow_{lv+1} adds to its loss gradient; weight gradient
             up.run(gup, dims[lv], e["gflow"][lv + 1], 1.0, accumulate=True)
-            up.wgrad(gup, dims[lv], e["flow"][lv + 1], dims[lv + 1])
+            wgrad(up, gup, dims[lv], e["flow"][lv + 1], dims[lv + 1])
             # deconv: LeakyReLU mask, then backward-data (conv form of the adjoint) opens the gradient of the level below
             mask(gdec, feat.slice(skipc, dm), 0.1)
             dec.run(gdec, dims[lv], gbelow, 1.0)
-            dec.wgrad(gdec, dims[lv], below, dims[lv + 1])
+            wgrad(dec, gdec, dims[lv], below, dims[lv + 1])
         # ---- encoder, deep to shallow ----
         prev = {n: (ENC[i - 1][0] if i else None) for i, (n, _, _) in enumerate(ENC)}
         for name, k, s in reversed(ENC):
@@ -232,10 +309,12 @@ class FlowNetS3D(nn.Module):
             bn.backward(e["raw"][name].view2d(), gact[name].view2d(), e["graw"][name].view2d())
             src = act[prev[name]] if prev[name] else e["x0"]
             odims = e["raw"][name].dims
-            lay.wgrad(src, src.dims, e["graw"][name], odims)
+            wgrad(lay, src, src.dims, e["graw"][name], odims)
             if prev[name]:
                 # skip tensors already hold the decoder's contribution (they are concat slices): accumulate there
                 lay.dgrad(e["graw"][name], odims, gact[prev[name]], src.dims, accumulate=prev[name] in ("conv2", "conv3_1", "conv4_1", "conv5_1"))
+        if side is not None:
+            main.wait_stream(side)
         # ---- gradients in named_parameters() order ----
         grads, pairs = [], []
         gbuf = e.setdefault("gbuf", {})                       # persistent gradient buffers: stable pointers = cached job tables, capturable
@@ -249,15 +328,16 @@ class FlowNetS3D(nn.Module):
             if pair[i] is None:
                 pair[i] = torch.empty_like(like, dtype=torch.float32)
             return pair[i]
-        conv_of = {}
-        for name, _, _ in ENC:
-            conv_of[f"{name}.0.weight"] = L[name]
-        for lv in (6, 5, 4, 3, 2):
-            conv_of[f"predict_flow{lv}.weight"] = L[f"predict_flow{lv}"]
-        for lv in (5, 4, 3, 2):
-            conv_of[f"deconv{lv}.0.weight"] = L[f"deconv{lv}"]
-            conv_of[f"upsampled_flow{lv + 1}_to_{lv}.weight"] = L[f"up{lv}"]
+        conv_of = self._conv_of(L)
+        if self._fidx:
+            if e.get("slab_pending"):
+                raise RuntimeError("FlowNetS3D: a second backward before optimizer.step(): with mireg.Adam(fuse=...) the weight gradients "
+                                   "live in the backward-weights slabs, which one backward fills and one step consumes")
+            e["slab_pending"], self._fe = True, e
         for pname, p in self._named():
+            if pname in self._fidx:                                                  # updated from its slab by fused_step
+                grads.append(None)
+                continue
             if pname == "conv1.0.weight":
                 g = e["g1s"] = gb("g1s", e["w1s"])                                    # gradient in the stem layout, mapped back below
                 pairs.append((conv_of[pname], g))

@@ -4,7 +4,7 @@ Adam(lr, betas=(0.9, 0.999), eps=1e-4) (train.py:129).  The 2-D train
 """
 from __future__ import annotations
 
-from typing import Iterable, Tuple
+from typing import Iterable, Optional, Tuple
 
 import torch
 
@@ -16,7 +16,11 @@ class Adam:
     CHUNK = 1 << 18
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8):
+                 eps: float = 1e-8, fuse: Optional[torch.nn.Module] = None):
+        """fuse: a module (tree) whose HIP-engine sub-modules offer `fuse_optimizer` (mireg.FlowNetS3D): their convolution weights
+        are then updated in the packed domain -- split-K gradient slabs -> Adam on the fp32 master weights -> refreshed bf16 forward
+        packs in one pass (`mireg_adam_pack`), so the torch-layout gradient of those weights is never written (`.grad` stays None)
+        and the next forward does not re-pack them.  Same update, same state; one backward per step."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")
@@ -33,6 +37,19 @@ class Adam:
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self._tab = None
+        self._fused = []
+        if fuse is not None:
+            index = {id(p): i for i, p in enumerate(self.params)}
+            for mod in fuse.modules():
+                if hasattr(mod, "fuse_optimizer"):
+                    mod.fuse_optimizer(self, index)
+                    self._fused.append(mod)
+            if not self._fused:
+                raise ValueError("mireg.Adam(fuse=...): no sub-module with a packed-domain optimizer hook in that module")
+
+    def state_ptrs(self, i: int) -> Tuple[int, int]:
+        """Device addresses of parameter i's first / second moment slices (for the packed-domain kernels)."""
+        return self.m.data_ptr() + 4 * self.offs[i], self.v.data_ptr() + 4 * self.offs[i]
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         """Default: keep the gradient tensors and zero them (one fill per tensor).  torch.optim's default drops them instead; with
@@ -57,8 +74,15 @@ class Adam:
                     o = 4 * c0
                     jobs.append(AdamJob(p.data_ptr() + o, g.data_ptr() + o, self.m.data_ptr() + 4 * off + o,
                                         self.v.data_ptr() + 4 * off + o, min(self.CHUNK, n - c0)))
-        if not jobs:
+        pending = [mod for mod in self._fused if mod.fused_pending()]
+        if not jobs and not pending:
             return
-        self._tab, self._keep = upload_table(jobs, self.params[0].device), keep       # alive until the launch has run
-        _lib.call("mireg_adam_step", self._tab.data_ptr(), len(jobs), self.step_dev.data_ptr(), 1, self.lr, self.betas[0],
-                  self.betas[1], self.eps, 1.0, _stream())
+        tick = 1
+        if jobs:
+            self._tab, self._keep = upload_table(jobs, self.params[0].device), keep       # alive until the launch has run
+            _lib.call("mireg_adam_step", self._tab.data_ptr(), len(jobs), self.step_dev.data_ptr(), tick, self.lr, self.betas[0],
+                      self.betas[1], self.eps, 1.0, _stream())
+            tick = 0
+        for mod in pending:                                   # same step count: only the first launch of a step ticks it
+            mod.fused_step(self, tick)
+            tick = 0

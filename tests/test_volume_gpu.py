@@ -334,3 +334,57 @@ def test_flownets3d_train_step_captures_into_a_hipgraph_and_replays_like_eager()
     for (k, a), (_, b) in zip(ma.named_parameters(), mb.named_parameters()):
         assert torch.isfinite(b).all()
         assert (a - b).abs().max().item() <= 1e-5 + 1e-4 * a.abs().max().item(), k
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_flownets3d_packed_domain_adam_matches_the_plain_optimizer(precision):
+    """mireg.Adam(fuse=model): the convolution weights are updated from their backward-weights slabs (`mireg_adam_pack`: slab ->
+    Adam on the fp32 master weights -> refreshed forward pack) instead of slab -> torch-layout gradient -> mireg_adam_step ->
+    re-pack.  Same sums in the same order: after four steps both models hold the same parameters and produce the same flows; the
+    fused weights never get a `.grad`; a second backward before step() is refused; a load_state_dict between steps is seen."""
+    import mireg
+    x = torch.rand(2, 2, 64, 64, 64, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def build(fuse):
+        torch.manual_seed(9)
+        m = mireg.opticalFlowReg3d(precision=precision, width_div=8).to(DEV).train()
+        return m, mireg.Adam(m.parameters(), 1e-3, eps=1e-4, fuse=m if fuse else None)
+
+    def step(m, opt):
+        flows, warped = m(x)
+        loss = mireg.OFEloss3d(flows, warped, x[:, 0:1])[3]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    (ma, oa), (mb, ob) = build(False), build(True)
+    for _ in range(4):
+        la, lb = step(ma, oa), step(mb, ob)
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.isfinite(b).all()
+        assert (a - b).abs().max().item() <= 1e-7 + 1e-6 * a.abs().max().item(), k
+        if b.dim() == 5 and not k.endswith("conv1.0.weight"):
+            assert b.grad is None, k
+        else:
+            assert b.grad is not None, k
+    assert int(oa.step_dev.item()) == int(ob.step_dev.item()) == 4
+    with torch.no_grad():                                      # the refreshed forward packs are the ones the next forward uses
+        ma.eval(), mb.eval()
+        fa, fb = ma(x)[0][0], mb(x)[0][0]
+    assert (fa - fb).abs().max().item() <= 1e-6 + 1e-5 * fa.abs().max().item()
+    # a parameter write between step() and the next forward invalidates the fresh packs
+    ma.train(), mb.train()
+    step(ma, oa), step(mb, ob)
+    sd = {k: v * 0.5 for k, v in ma.state_dict().items() if v.dtype.is_floating_point}
+    ma.load_state_dict(sd, strict=False), mb.load_state_dict(sd, strict=False)
+    la, lb = step(ma, oa), step(mb, ob)
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
+    # one backward fills the slabs, one step consumes them
+    flows, warped = mb(x)
+    mireg.OFEloss3d(flows, warped, x[:, 0:1])[3].backward()
+    flows, warped = mb(x)
+    with pytest.raises(RuntimeError, match="second backward"):
+        mireg.OFEloss3d(flows, warped, x[:, 0:1])[3].backward()
