@@ -326,6 +326,9 @@ typedef struct mireg_pack3d_job {
   int unit0;
 } mireg_pack3d_job;
 int mireg_pack_dgrad3d(const mireg_pack3d_job* jobs_dev, int njobs, int total_units, int dtype, hipStream_t stream);
+/* The same packs from the layers' FWD packs (mireg_pack_weights / mireg_adam_pack output, element type = dtype) instead of the fp32
+ * weights: job.src = FWD pack [Co][taps*Cip], Cip = Ci rounded up to 8; units = taps * ceil(Cop/64) * ceil(Ci/64) per job. */
+int mireg_pack_dgrad3d_fwd(const mireg_pack3d_job* jobs_dev, int njobs, int total_units, int dtype, hipStream_t stream);
 
 /* ---- two-output-channel 3x3 / stride 1 / pad 1 convolutions (predict_flow heads: FlowNetS/util.py:33-34,
  * flownet2/networks/submodules.py:32-33, PWC/models/PWCNet.py:31-32) on the vector ALUs.  w = the FWD pack

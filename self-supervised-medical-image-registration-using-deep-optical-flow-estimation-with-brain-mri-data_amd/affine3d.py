@@ -181,16 +181,22 @@ class Conv3dLayer:
         return j
 
     @staticmethod
-    def pack_dgrad_table(layers, ws: Workspace) -> torch.Tensor:
-        """One launch for the backward-data packs of `layers`; marks them fresh (dgrad() repacks a stale layer on its own)."""
+    def pack_dgrad_table(layers, ws: Workspace, from_fwd: bool = False) -> torch.Tensor:
+        """One launch for the backward-data packs of `layers`; marks them fresh (dgrad() repacks a stale layer on its own).
+        from_fwd: the layers' forward packs are current (just packed / rewritten by the packed-domain optimizer): transpose
+        those (half the bytes, whole-line accesses) instead of gathering from the fp32 weights."""
         jobs, u = [], 0
         for l in layers:
             j = l.pack3d_job()
             j.unit0 = u
-            u += l.Ci * ((rup(l.Co, 8) + 63) // 64)
+            if from_fwd:
+                j.src = l.packF.data_ptr()
+                u += l.kd * l.kh * l.kw * ((rup(l.Co, 8) + 63) // 64) * ((l.Ci + 63) // 64)
+            else:
+                u += l.Ci * ((rup(l.Co, 8) + 63) // 64)
             jobs.append(j)
         tab = upload_table(jobs, ws.device)
-        _lib.call("mireg_pack_dgrad3d", tab.data_ptr(), len(jobs), u, ws.code, _stream())
+        _lib.call("mireg_pack_dgrad3d_fwd" if from_fwd else "mireg_pack_dgrad3d", tab.data_ptr(), len(jobs), u, ws.code, _stream())
         for l in layers:
             l.dfresh = True
         return tab

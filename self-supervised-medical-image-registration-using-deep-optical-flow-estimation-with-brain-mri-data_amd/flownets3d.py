@@ -220,7 +220,7 @@ class FlowNetS3D(nn.Module):
         _lib.call("mireg_pack_weights", tab.data_ptr(), len(jobs), units, dunits, ws.code, st)
         # backward-data packs: the deconvolutions / flow upsamplers run that form forward, every other layer (bar conv1) backward
         need = [l for n, l in L.items() if n != "conv1" and (keep or n.startswith(("deconv", "up")))]
-        e["_tab3"] = Conv3dLayer.pack_dgrad_table(need, ws)
+        e["_tab3"] = Conv3dLayer.pack_dgrad_table(need, ws, from_fwd=True)              # every forward pack is current at this point
         _lib.call("mireg_stem3d_gather", x.data_ptr(), e["x0"].ptr, B, 2, D, H, W, 7, 2, 3, 16, ws.code, st)
         src, training = e["x0"], self.training
         for name, k, s in ENC:
