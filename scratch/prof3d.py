@@ -9,7 +9,7 @@ g = torch.Generator(device="cpu").manual_seed(6)
 low = torch.rand(8, 2, 8, 8, 8, generator=g)
 vol = torch.nn.functional.interpolate(low, size=(128, 128, 128), mode="trilinear", align_corners=False).to(dev)
 reg3 = mireg.opticalFlowReg3d(precision="bf16").to(dev).train()
-opt = mireg.Adam(reg3.parameters(), 1e-4, eps=1e-4)
+opt = mireg.Adam(reg3.parameters(), 1e-4, eps=1e-4, fuse=reg3)
 for it in range(4):
     torch.cuda.synchronize()
     t0 = time.perf_counter()

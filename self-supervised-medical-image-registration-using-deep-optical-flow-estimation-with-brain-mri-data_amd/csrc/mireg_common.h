@@ -47,13 +47,15 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float* red) {
   }
 }
 
-// Charbonnier penalty (x^2 + eps^2)^0.25 with eps = 1e-9 (reference loss.py:33-35)
-__device__ __forceinline__ float charb(float d) { return sqrtf(sqrtf(d * d + 1e-18f)); }
+// Charbonnier penalty (x^2 + eps^2)^0.25 with eps = 1e-9 (reference loss.py:33-35).  The argument of every root here lies in
+// [1e-18, 1e18]: normal floats, so the bare v_sqrt_f32 / v_rsq_f32 (1 ulp) replace sqrtf / rsqrtf, whose denormal scaling and
+// refinement steps cost ~25 vector instructions each and made the smoothness kernels ALU-bound (47 -> ~8 instructions per term).
+__device__ __forceinline__ float charb(float d) { return __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(d * d + 1e-18f)); }
 // d/dd of the above: 0.5 * d * (d^2 + eps^2)^(-0.75)
 __device__ __forceinline__ float charb_grad(float d) {
   const float t = d * d + 1e-18f;
-  const float r = rsqrtf(t);           // t^-0.5
-  return 0.5f * d * r * sqrtf(r);      // t^-0.75
+  const float r = __builtin_amdgcn_rsqf(t);                 // t^-0.5
+  return 0.5f * d * r * __builtin_amdgcn_sqrtf(r);          // t^-0.75
 }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }

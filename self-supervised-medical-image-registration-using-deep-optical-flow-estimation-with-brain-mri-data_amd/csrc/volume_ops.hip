@@ -22,6 +22,32 @@ inline int grid_for(long work, int cap = 4096) {
   return (int)g;
 }
 
+// Grid-stride loops over (plane, z, y, x) without per-element 64-bit divisions (each costs tens of instructions; five of them per
+// voxel made these kernels ALU-bound at 128^3): the flat index is split once and then advanced by the loop stride in mixed radix.
+struct Vox { int x, y, z, p; };
+inline Vox vox_step(long stride, int w, int h, int d) {               // host: the stride's digits
+  Vox s;
+  s.x = (int)(stride % w); stride /= w;
+  s.y = (int)(stride % h); stride /= h;
+  s.z = (int)(stride % d);
+  s.p = (int)(stride / d);
+  return s;
+}
+__device__ __forceinline__ Vox vox_split(long i, int w, int h, int d) {
+  Vox v;
+  v.x = (int)(i % w); i /= w;
+  v.y = (int)(i % h); i /= h;
+  v.z = (int)(i % d);
+  v.p = (int)(i / d);
+  return v;
+}
+__device__ __forceinline__ void vox_advance(Vox& v, const Vox& s, int w, int h, int d) {
+  v.x += s.x; int c = v.x >= w; v.x -= c ? w : 0;
+  v.y += s.y + c; c = v.y >= h; v.y -= c ? h : 0;
+  v.z += s.z + c; c = v.z >= d; v.z -= c ? d : 0;
+  v.p += s.p + c;
+}
+
 // same op order as ATen's area_pixel_compute_source_index (linear modes)
 __device__ __forceinline__ void src_coord(int dst, float scale, int align, int in_size, int& i0, int& i1, float& l1) {
   float s = align ? (float)dst * scale : fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
@@ -47,11 +73,13 @@ inline float host_scale(int in, int out, int align) {
 // ---- trilinear resize -----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads)
 resize3d_fwd_kernel(const float* __restrict__ in, long isn, long isc, long isp, float* __restrict__ out, int N, int C,
-                    int D, int H, int W, int d, int h, int w, float sz, float sy, float sx, int align) {
+                    int D, int H, int W, int d, int h, int w, float sz, float sy, float sx, int align, Vox step) {
   const long ovox = (long)d * h * w, total = (long)N * C * ovox;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % w), y = (int)((i / w) % h), z = (int)((i / ((long)w * h)) % d);
-    const int c = (int)((i / ovox) % C), n = (int)(i / (ovox * C));
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Vox q = vox_split(i, w, h, d);
+  for (; i < total; i += (long)gridDim.x * blockDim.x, vox_advance(q, step, w, h, d)) {
+    const int x = q.x, y = q.y, z = q.z;
+    const int n = q.p / C, c = q.p - n * C;
     int z0, z1, y0, y1, x0, x1;
     float lz, ly, lx;
     src_coord(z, sz, align, D, z0, z1, lz);
@@ -110,11 +138,13 @@ resize3d_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, lon
 // (batch, channel, voxel) addressing of gin and applies beta.
 __global__ void __launch_bounds__(kThreads)
 resize1d_bwd_kernel(const float* __restrict__ src, float* __restrict__ dst, long outer, int Lout, int Lin, long inner, float scale,
-                    int align, int strided, long isn, long isc, long isp, int C, float beta) {
+                    int align, int strided, long isn, long isc, long isp, int C, float beta, Vox step) {
   const long total = outer * Lin * inner;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long in_ = i % inner, o = i / (inner * Lin);
-    const int P = (int)((i / inner) % Lin);
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Vox qv = vox_split(i, (int)inner, Lin, 0x7fffffff);                  // x = inner index, y = P, z = outer index (no carry out)
+  for (; i < total; i += (long)gridDim.x * blockDim.x, vox_advance(qv, step, (int)inner, Lin, 0x7fffffff)) {
+    const long in_ = qv.x, o = qv.z;
+    const int P = qv.y;
     int lo, hi;
     out_range(P, scale, align, Lout, lo, hi);
     const float* s = src + (o * Lout) * inner + in_;
@@ -127,7 +157,7 @@ resize1d_bwd_kernel(const float* __restrict__ src, float* __restrict__ dst, long
     }
     if (!strided) dst[i] = acc;
     else {
-      const long n = o / C, c = o - n * C;
+      const int n = (int)o / C, c = (int)o - n * C;
       float* d = dst + n * isn + c * isc + ((long)P * inner + in_) * isp;
       *d = beta != 0.f ? *d * beta + acc : acc;
     }
@@ -164,12 +194,13 @@ __device__ __forceinline__ float tap3(const float* __restrict__ img, int x, int 
 
 __global__ void __launch_bounds__(kThreads)
 stn3d_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, const float* __restrict__ frame,
-                 float* __restrict__ warped, int B, int C, int d, int h, int w) {
+                 float* __restrict__ warped, int B, int C, int d, int h, int w, Vox step) {
   const long nvox = (long)d * h * w, total = (long)B * nvox;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / nvox);
-    const long v = i - (long)b * nvox;
-    const int x = (int)(v % w), y = (int)((v / w) % h), z = (int)(v / ((long)w * h));
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Vox q = vox_split(i, w, h, d);
+  for (; i < total; i += (long)gridDim.x * blockDim.x, vox_advance(q, step, w, h, d)) {
+    const int b = q.p, x = q.x, y = q.y, z = q.z;
+    const long v = ((long)z * h + y) * w + x;
     const Taps3 t = taps_for(flow + b * fsb + v * fsp, fsc, x, y, z, d, h, w);
     for (int c = 0; c < C; ++c) {
       const float* img = frame + ((long)b * C + c) * nvox;
@@ -187,13 +218,14 @@ stn3d_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, c
 // gflow planar (B,3,d,h,w): channel a = d/d flow_a = sum_c gout_c * d sample / d p_a * (n_a - 1)/n_a
 __global__ void __launch_bounds__(kThreads)
 stn3d_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, const float* __restrict__ frame,
-                 const float* __restrict__ gout, float* __restrict__ gflow, float beta, int B, int C, int d, int h, int w) {
+                 const float* __restrict__ gout, float* __restrict__ gflow, float beta, int B, int C, int d, int h, int w, Vox step) {
   const long nvox = (long)d * h * w, total = (long)B * nvox;
   const float kx = (float)(w - 1) / (float)w, ky = (float)(h - 1) / (float)h, kz = (float)(d - 1) / (float)d;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / nvox);
-    const long v = i - (long)b * nvox;
-    const int x = (int)(v % w), y = (int)((v / w) % h), z = (int)(v / ((long)w * h));
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Vox q = vox_split(i, w, h, d);
+  for (; i < total; i += (long)gridDim.x * blockDim.x, vox_advance(q, step, w, h, d)) {
+    const int b = q.p, x = q.x, y = q.y, z = q.z;
+    const long v = ((long)z * h + y) * w + x;
     const Taps3 t = taps_for(flow + b * fsb + v * fsp, fsc, x, y, z, d, h, w);
     float gx = 0.f, gy = 0.f, gz = 0.f;
     for (int c = 0; c < C; ++c) {
@@ -223,14 +255,16 @@ stn3d_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, c
 constexpr float kChan = 2.f / 3.f;
 
 __global__ void __launch_bounds__(kThreads)
-smooth3d_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, double* __restrict__ sum, int B, int d, int h, int w) {
+smooth3d_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, double* __restrict__ sum, int B, int d, int h, int w,
+                    Vox step) {
   __shared__ float red[kThreads / 64];
   const long nvox = (long)d * h * w, total = (long)B * nvox;
   float acc[1] = {0.f};
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / nvox);
-    const long v = i - (long)b * nvox;
-    const int x = (int)(v % w), y = (int)((v / w) % h), z = (int)(v / ((long)w * h));
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Vox q = vox_split(i, w, h, d);
+  for (; i < total; i += (long)gridDim.x * blockDim.x, vox_advance(q, step, w, h, d)) {
+    const int b = q.p, x = q.x, y = q.y, z = q.z;
+    const long v = ((long)z * h + y) * w + x;
     const float* f = flow + b * fsb + v * fsp;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -247,14 +281,15 @@ smooth3d_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp
 
 __global__ void __launch_bounds__(kThreads)
 smooth3d_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, const float* __restrict__ coef,
-                    float* __restrict__ gflow, float beta, int B, int d, int h, int w) {
+                    float* __restrict__ gflow, float beta, int B, int d, int h, int w, Vox step) {
   const float cs = coef[5] * kChan;
   const long nvox = (long)d * h * w, total = (long)B * nvox;
   const long sz = (long)h * w * fsp, sy = (long)w * fsp;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / nvox);
-    const long v = i - (long)b * nvox;
-    const int x = (int)(v % w), y = (int)((v / w) % h), z = (int)(v / ((long)w * h));
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Vox q = vox_split(i, w, h, d);
+  for (; i < total; i += (long)gridDim.x * blockDim.x, vox_advance(q, step, w, h, d)) {
+    const int b = q.p, x = q.x, y = q.y, z = q.z;
+    const long v = ((long)z * h + y) * w + x;
     const float* f = flow + b * fsb + v * fsp;
     float* g = gflow + (long)b * 3 * nvox + v;
 #pragma unroll
@@ -280,32 +315,33 @@ smooth3d_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 stem3d_gather_kernel(const float* __restrict__ x, T* __restrict__ dst, int B, int C, int D, int H, int W, int Wo, int k, int stride,
-                     int pad, int Cpad) {
+                     int pad, int Cpad, Vox step) {
   // one thread per (voxel, 8-channel granule): consecutive threads write consecutive 16/32-byte granules
   const int gpv = Cpad / 8;
   const long total = (long)B * D * H * Wo * gpv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int g = (int)(i % gpv);
-    long r = i / gpv;
-    const int xo = (int)(r % Wo); r /= Wo;
-    const int y = (int)(r % H); r /= H;
-    const int z = (int)(r % D);
-    const int b = (int)(r / D);
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Vox q = vox_split(i, Wo * gpv, H, D);                                // x digit = (xo, granule)
+  for (; i < total; i += (long)gridDim.x * blockDim.x, vox_advance(q, step, Wo * gpv, H, D)) {
+    const int xo = q.x / gpv, g = q.x - xo * gpv;
+    const int y = q.y, z = q.z, b = q.p;
     const float* row = x + (((long)b * C * D + z) * H + y) * W;          // channel c adds c * D*H*W
-    T v[8];
+    alignas(16) T v[8];
+    int tx = (g * 8) / C, c = g * 8 - tx * C;                          // (tap, channel) of the granule's first element, then counted up
+    const long cstride = (long)D * H * W;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int cp = g * 8 + e;
       float f = 0.f;
-      if (cp < k * C) {
-        const int tx = cp / C, c = cp - tx * C, xi = xo * stride + tx - pad;
-        if (xi >= 0 && xi < W) f = row[(long)c * D * H * W + xi];
-      }
+      const int xi = xo * stride + tx - pad;
+      if (tx < k && xi >= 0 && xi < W) f = row[c * cstride + xi];
       v[e] = (T)f;
+      if (++c == C) { c = 0; ++tx; }
     }
-    T* d = dst + i * 8;
+    if constexpr (sizeof(T) == 2) *reinterpret_cast<uint4*>(dst + i * 8) = *reinterpret_cast<const uint4*>(v);   // one 16-byte store
+    else {
+      T* d = dst + i * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) d[e] = v[e];
+      for (int e = 0; e < 8; ++e) d[e] = v[e];
+    }
   }
 }
 
@@ -316,9 +352,10 @@ extern "C" {
 int mireg_resize_trilinear_fwd(const float* in, long isn, long isc, long isp, float* out, int N, int C, int D, int H, int W,
                                int d, int h, int w, int align_corners, hipStream_t stream) {
   MIREG_CHECK_ARG(in && out && N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && d > 0 && h > 0 && w > 0);
-  hipLaunchKernelGGL(resize3d_fwd_kernel, dim3(grid_for((long)N * C * d * h * w)), dim3(kThreads), 0, stream, in, isn, isc, isp, out,
+  const int g = grid_for((long)N * C * d * h * w);
+  hipLaunchKernelGGL(resize3d_fwd_kernel, dim3(g), dim3(kThreads), 0, stream, in, isn, isc, isp, out,
                      N, C, D, H, W, d, h, w, host_scale(D, d, align_corners), host_scale(H, h, align_corners),
-                     host_scale(W, w, align_corners), align_corners);
+                     host_scale(W, w, align_corners), align_corners, vox_step((long)g * kThreads, w, h, d));
   MIREG_LAUNCH_RET();
 }
 
@@ -338,44 +375,51 @@ int mireg_resize_trilinear_bwd_sep(const float* gout, float* gin, long isn, long
   MIREG_CHECK_ARG(ws_elems >= e1 + e2);
   float* t1 = ws;                                                    // [N*C*d*h][W]
   float* t2 = ws + e1;                                               // [N*C*d][H][W]
-  hipLaunchKernelGGL(resize1d_bwd_kernel, dim3(grid_for(e1)), dim3(kThreads), 0, stream, gout, t1, nc * d * h, w, W, 1L,
-                     host_scale(W, w, align_corners), align_corners, 0, 0L, 0L, 0L, C, 0.f);
-  hipLaunchKernelGGL(resize1d_bwd_kernel, dim3(grid_for(e2)), dim3(kThreads), 0, stream, (const float*)t1, t2, nc * d, h, H, (long)W,
-                     host_scale(H, h, align_corners), align_corners, 0, 0L, 0L, 0L, C, 0.f);
-  hipLaunchKernelGGL(resize1d_bwd_kernel, dim3(grid_for(nc * D * H * W)), dim3(kThreads), 0, stream, (const float*)t2, gin, nc, d, D,
-                     (long)H * W, host_scale(D, d, align_corners), align_corners, 1, isn, isc, isp, C, beta);
+  MIREG_CHECK_ARG((long)H * W < 0x7fffffffL && nc * d * h < 0x7fffffffL);
+  const int g1 = grid_for(e1), g2 = grid_for(e2), g3 = grid_for(nc * D * H * W);
+  hipLaunchKernelGGL(resize1d_bwd_kernel, dim3(g1), dim3(kThreads), 0, stream, gout, t1, nc * d * h, w, W, 1L,
+                     host_scale(W, w, align_corners), align_corners, 0, 0L, 0L, 0L, C, 0.f, vox_step((long)g1 * kThreads, 1, W, 0x7fffffff));
+  hipLaunchKernelGGL(resize1d_bwd_kernel, dim3(g2), dim3(kThreads), 0, stream, (const float*)t1, t2, nc * d, h, H, (long)W,
+                     host_scale(H, h, align_corners), align_corners, 0, 0L, 0L, 0L, C, 0.f, vox_step((long)g2 * kThreads, W, H, 0x7fffffff));
+  hipLaunchKernelGGL(resize1d_bwd_kernel, dim3(g3), dim3(kThreads), 0, stream, (const float*)t2, gin, nc, d, D,
+                     (long)H * W, host_scale(D, d, align_corners), align_corners, 1, isn, isc, isp, C, beta,
+                     vox_step((long)g3 * kThreads, H * W, D, 0x7fffffff));
   MIREG_LAUNCH_RET();
 }
 
 int mireg_stn3d_fwd(const float* flow, long fsb, long fsc, long fsp, const float* frame, float* warped, int B, int C, int d,
                     int h, int w, hipStream_t stream) {
   MIREG_CHECK_ARG(flow && frame && warped && B > 0 && C > 0 && d > 0 && h > 0 && w > 0);
-  hipLaunchKernelGGL(stn3d_fwd_kernel, dim3(grid_for((long)B * d * h * w)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame,
-                     warped, B, C, d, h, w);
+  const int g = grid_for((long)B * d * h * w);
+  hipLaunchKernelGGL(stn3d_fwd_kernel, dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame,
+                     warped, B, C, d, h, w, vox_step((long)g * kThreads, w, h, d));
   MIREG_LAUNCH_RET();
 }
 
 int mireg_stn3d_bwd(const float* flow, long fsb, long fsc, long fsp, const float* frame, const float* gout, float* gflow,
                     float beta, int B, int C, int d, int h, int w, hipStream_t stream) {
   MIREG_CHECK_ARG(flow && frame && gout && gflow && B > 0 && C > 0 && d > 0 && h > 0 && w > 0);
-  hipLaunchKernelGGL(stn3d_bwd_kernel, dim3(grid_for((long)B * d * h * w)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame,
-                     gout, gflow, beta, B, C, d, h, w);
+  const int g = grid_for((long)B * d * h * w);
+  hipLaunchKernelGGL(stn3d_bwd_kernel, dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, frame,
+                     gout, gflow, beta, B, C, d, h, w, vox_step((long)g * kThreads, w, h, d));
   MIREG_LAUNCH_RET();
 }
 
 int mireg_smoothness3d_fwd(const float* flow, long fsb, long fsc, long fsp, double* sum, int B, int d, int h, int w,
                            hipStream_t stream) {
   MIREG_CHECK_ARG(flow && sum && B > 0 && d > 0 && h > 0 && w > 0);
-  hipLaunchKernelGGL(smooth3d_fwd_kernel, dim3(grid_for((long)B * d * h * w, 1024)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp,
-                     sum, B, d, h, w);
+  const int g = grid_for((long)B * d * h * w, 1024);
+  hipLaunchKernelGGL(smooth3d_fwd_kernel, dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp,
+                     sum, B, d, h, w, vox_step((long)g * kThreads, w, h, d));
   MIREG_LAUNCH_RET();
 }
 
 int mireg_smoothness3d_bwd(const float* flow, long fsb, long fsc, long fsp, const float* coef, float* gflow, float beta, int B,
                            int d, int h, int w, hipStream_t stream) {
   MIREG_CHECK_ARG(flow && coef && gflow && B > 0 && d > 0 && h > 0 && w > 0);
-  hipLaunchKernelGGL(smooth3d_bwd_kernel, dim3(grid_for((long)B * d * h * w)), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, coef,
-                     gflow, beta, B, d, h, w);
+  const int g = grid_for((long)B * d * h * w);
+  hipLaunchKernelGGL(smooth3d_bwd_kernel, dim3(g), dim3(kThreads), 0, stream, flow, fsb, fsc, fsp, coef,
+                     gflow, beta, B, d, h, w, vox_step((long)g * kThreads, w, h, d));
   MIREG_LAUNCH_RET();
 }
 
@@ -387,12 +431,14 @@ int mireg_stem3d_gather(const float* x, void* dst, int B, int C, int D, int H, i
   const int Wo = (W + 2 * pad - k) / stride + 1;
   MIREG_CHECK_ARG(Wo > 0);
   const long total = (long)B * D * H * Wo * (Cpad / 8);
+  const int g = grid_for(total, 16384);
+  const Vox step = vox_step((long)g * kThreads, Wo * (Cpad / 8), H, D);
   if (dtype == MIREG_DTYPE_BF16)
-    hipLaunchKernelGGL((stem3d_gather_kernel<__bf16>), dim3(grid_for(total, 16384)), dim3(kThreads), 0, stream, x,
-                       reinterpret_cast<__bf16*>(dst), B, C, D, H, W, Wo, k, stride, pad, Cpad);
+    hipLaunchKernelGGL((stem3d_gather_kernel<__bf16>), dim3(g), dim3(kThreads), 0, stream, x,
+                       reinterpret_cast<__bf16*>(dst), B, C, D, H, W, Wo, k, stride, pad, Cpad, step);
   else
-    hipLaunchKernelGGL((stem3d_gather_kernel<float>), dim3(grid_for(total, 16384)), dim3(kThreads), 0, stream, x,
-                       reinterpret_cast<float*>(dst), B, C, D, H, W, Wo, k, stride, pad, Cpad);
+    hipLaunchKernelGGL((stem3d_gather_kernel<float>), dim3(g), dim3(kThreads), 0, stream, x,
+                       reinterpret_cast<float*>(dst), B, C, D, H, W, Wo, k, stride, pad, Cpad, step);
   MIREG_LAUNCH_RET();
 }
 
