@@ -339,7 +339,7 @@ correlation_bwd_kernel(const T* __restrict__ g, long ldg, const T* __restrict__ 
 // so one A fragment feeds all of a wave's MFMAs of a K-step.  Same sums as correlation_bwd_kernel, fp32 accumulate.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-template <int WHICH, int NTW>
+template <int WHICH, int NTW, int NB>
 __global__ void __launch_bounds__(256)
 correlation_bwd_mfma_kernel(const __bf16* __restrict__ g, long ldg, const __bf16* __restrict__ fo, long ldo_, __bf16* __restrict__ dout,
                             long ldd, int B, int H, int W, int C, int c_norm, int R, int s2, int accumulate, int KW, int LDB) {
@@ -369,62 +369,59 @@ correlation_bwd_mfma_kernel(const __bf16* __restrict__ g, long ldg, const __bf16
 
   // The band's nonzero pattern (which (m, kk) pair up) does not depend on dyi: zero the tile once, rewrite only the band.
   for (int e = threadIdx.x; e < 32 * LDA; e += 256) At[e] = (__bf16)0.f;
-  constexpr int NB = 14, NA = 4;                                   // register staging: 256 * NB granules >= KW * cgran, 256 * NA >= 32 * D
-  uint4 breg[NB];
-  __bf16 areg[NA];
-  auto fetch = [&](int dyi) {                                      // global loads only (branch-free), consumed one iteration later
+  constexpr int NA = 4;                                            // register staging: 256 * NB granules >= KW * cgran, 256 * NA >= 32 * D
+  // two register sets: the loads of row dyi + 2 are issued while row dyi is multiplied, so a row's global-load latency is hidden
+  // behind two rows of staging + MFMA instead of one (the loop was one memory round trip per displacement row)
+  // (only where a row is few granules per thread: with 14 slots a second set would not fit the register file)
+  constexpr bool TWO = NB <= 5;
+  uint4 breg0[NB], breg1[TWO ? NB : 1];
+  __bf16 areg0[NA], areg1[TWO ? NA : 1];
+  // Per-slot addressing is fixed for the whole block: source offset (0 = a harmless in-range dummy for masked slots), LDS destination
+  // (-1 = none) and the zero mask are computed once, so fetch() is nothing but unconditional loads (straight-line code: the compiler
+  // turned per-slot conditions into a branch and a full s_waitcnt per slot) and commit() a counted wait plus LDS stores.
+  int bsrc[NB], bdst[NB], asrc[NA], adst[NA];
+  unsigned bzero = 0u, azero = 0u;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int kk = e / cgran, cg = e - kk * cgran, k = klo + kk;
+    const bool in = e < KW * cgran, ok = in && k < W && cg * 8 < C;
+    bsrc[i] = ok ? k * (int)ldo_ + cg * 8 : 0;
+    bdst[i] = in ? kk * LDB + cg * 8 : -1;
+    if (!ok) bzero |= 1u << i;
+  }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int m = e / D, dxi = e - m * D, xm = x0 + m;
+    const int k = WHICH == 0 ? xm + (dxi - R) * s2 : xm - (dxi - R) * s2;       // the other map's pixel this entry pairs with
+    const bool ok = e < 32 * D && xm < W && k >= 0 && k < W;
+    asrc[i] = ok ? (WHICH == 0 ? xm : k) * (int)ldg + dxi : 0;
+    adst[i] = (e < 32 * D && k >= klo && k < klo + KW) ? m * LDA + (k - klo) : -1;
+    if (!ok) azero |= 1u << i;
+  }
+  auto fetch = [&](int dyi, auto& breg, auto& areg) {              // global loads only, consumed one or two iterations later
     const int yy = WHICH == 0 ? y + (dyi - R) * s2 : y - (dyi - R) * s2;
     const __bf16* frow = fo + (((long)b * H + yy) * W) * ldo_;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      breg[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (256 * i < KW * cgran) {                                   // block-uniform: few-channel levels fill 1..3 of the 14 slots
-        const int e = threadIdx.x + 256 * i;
-        const int kk = e / cgran, cg = e - kk * cgran, k = klo + kk;
-        const bool ok = e < KW * cgran && k < W && cg * 8 < C;
-        const uint4 v = *GPTR(const uint4, frow + (long)(ok ? k : 0) * ldo_ + (ok ? cg * 8 : 0));
-        if (ok) breg[i] = v;
-      }
-    }
-    const int gy = WHICH == 0 ? y : yy;
+    for (int i = 0; i < NB; ++i) breg[i] = *GPTR(const uint4, frow + bsrc[i]);
+    const __bf16* grow = g + (((long)b * H + (WHICH == 0 ? y : yy)) * W) * ldg + dyi * D;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      areg[i] = (__bf16)0.f;
-      if (256 * i < 32 * D) {                                       // block-uniform
-        const int e = threadIdx.x + 256 * i;
-        const int m = e / D, dxi = e - m * D, xm = x0 + m;
-        const int k = WHICH == 0 ? xm + (dxi - R) * s2 : xm - (dxi - R) * s2;   // the other map's pixel this entry pairs with
-        const bool ok = e < 32 * D && xm < W && k >= 0 && k < W;
-        const int gx = WHICH == 0 ? xm : k;
-        const __bf16 v = *GPTR(const __bf16, g + (((long)b * H + gy) * W + (ok ? gx : 0)) * ldg + (ok ? dyi * D + dxi : 0));
-        if (ok) areg[i] = v;
-      }
-    }
+    for (int i = 0; i < NA; ++i) areg[i] = *GPTR(const __bf16, grow + asrc[i]);
   };
-  auto commit = [&]() {                                            // registers -> LDS tiles
+  auto commit = [&](const auto& breg, const auto& areg) {          // registers -> LDS tiles
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int e = threadIdx.x + 256 * i;
-      if (e < KW * cgran) { const int kk = e / cgran, cg = e - kk * cgran; *reinterpret_cast<uint4*>(Bt + (long)kk * LDB + cg * 8) = breg[i]; }
-    }
+    for (int i = 0; i < NB; ++i)
+      if (bdst[i] >= 0) *reinterpret_cast<uint4*>(Bt + bdst[i]) = ((bzero >> i) & 1u) ? make_uint4(0u, 0u, 0u, 0u) : breg[i];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int e = threadIdx.x + 256 * i;
-      const int m = e / D, dxi = e - m * D, xm = x0 + m;
-      const int k = WHICH == 0 ? xm + (dxi - R) * s2 : xm - (dxi - R) * s2;
-      if (e < 32 * D && k >= klo && k < klo + KW) At[m * LDA + (k - klo)] = areg[i];
-    }
+    for (int i = 0; i < NA; ++i)
+      if (adst[i] >= 0) At[adst[i]] = ((azero >> i) & 1u) ? (__bf16)0.f : areg[i];
   };
   // valid displacement rows form one interval [d_lo, d_hi]
   int d_lo = 0, d_hi = D - 1;
   while (d_lo < D) { const int yy = WHICH == 0 ? y + (d_lo - R) * s2 : y - (d_lo - R) * s2; if (yy >= 0 && yy < H) break; ++d_lo; }
   while (d_hi >= 0) { const int yy = WHICH == 0 ? y + (d_hi - R) * s2 : y - (d_hi - R) * s2; if (yy >= 0 && yy < H) break; --d_hi; }
-  if (d_lo <= d_hi) fetch(d_lo);
-  for (int dyi = d_lo; dyi <= d_hi; ++dyi) {
-    __syncthreads();                                               // previous row's fragments are consumed (and the zero fill landed)
-    commit();
-    __syncthreads();
-    if (dyi < d_hi) fetch(dyi + 1);                                // next row's loads fly under this row's MFMAs
+  auto multiply = [&]() {
     for (int ks = 0; ks < nsteps; ++ks) {
       const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + r * LDA + ks * 16 + 8 * h);
 #pragma unroll
@@ -438,6 +435,31 @@ correlation_bwd_mfma_kernel(const __bf16* __restrict__ g, long ldg, const __bf16
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, v), acc[j], 0, 0, 0);
         }
       }
+    }
+  };
+  if (d_lo <= d_hi) fetch(d_lo, breg0, areg0);
+  if constexpr (TWO) {
+    if (d_lo + 1 <= d_hi) fetch(d_lo + 1, breg1, areg1);
+    for (int dyi = d_lo; dyi <= d_hi; dyi += 2) {
+      __syncthreads();                                             // previous row's fragments are consumed (and the zero fill landed)
+      commit(breg0, areg0);
+      __syncthreads();
+      if (dyi + 2 <= d_hi) fetch(dyi + 2, breg0, areg0);
+      multiply();
+      if (dyi + 1 > d_hi) break;
+      __syncthreads();
+      commit(breg1, areg1);
+      __syncthreads();
+      if (dyi + 3 <= d_hi) fetch(dyi + 3, breg1, areg1);
+      multiply();
+    }
+  } else {
+    for (int dyi = d_lo; dyi <= d_hi; ++dyi) {
+      __syncthreads();
+      commit(breg0, areg0);
+      __syncthreads();
+      if (dyi < d_hi) fetch(dyi + 1, breg0, areg0);                // next row's loads fly under this row's MFMAs
+      multiply();
     }
   }
 #pragma unroll
@@ -951,18 +973,26 @@ int mireg_correlation_bwd(const void* g, long ldg, const void* f1, long ld1, con
   if (dtype == MIREG_DTYPE_BF16 && C <= 512 && C % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && (uintptr_t)f1 % 16 == 0 && (uintptr_t)f2 % 16 == 0 &&
       (uintptr_t)g % 2 == 0 && units < (1L << 30)) {
     const int span = 32 + 2 * R * stride2 + 15;                                  // pixels a tile can pair with, from a 16-aligned start
-    const int KW = (span + 15) / 16 * 16;
+    // staged pixels start at a 16-aligned klo >= 0 and pixels >= W are zero: a narrow image needs no more than its own width
+    const int KW = ((span + 15) / 16 * 16) < ((W + 15) / 16 * 16) ? ((span + 15) / 16 * 16) : ((W + 15) / 16 * 16);
     const int LDB = (C + 31) / 32 * 32 + 8;
     const size_t lds = ((size_t)KW * LDB + 32 * (KW + 8)) * 2;
     const int ntw = ((C + 31) / 32 + 3) / 4;
-    if (lds <= 150 * 1024 && (long)KW * (LDB / 8) <= 256 * 14 && 32 * (2 * R + 1) <= 256 * 4) {
-#define MIREG_CORR_BWD(WHICH, NTW, gp, fo_, ldo__, dd, lddd, acc_) { \
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)correlation_bwd_mfma_kernel<WHICH, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((correlation_bwd_mfma_kernel<WHICH, NTW>), dim3((unsigned)units), dim3(256), lds, stream, (const __bf16*)gp, ldg, \
+    if (lds <= 150 * 1024 && (long)KW * (LDB / 8) <= 256 * 14 && 32 * (2 * R + 1) <= 256 * 4 && (long)W * ld1 < (1L << 30) && (long)W * ld2 < (1L << 30) &&
+        (long)W * ldg < (1L << 30)) {
+      const long slots = ((long)KW * (LDB / 8) + 255) / 256;                        // register slots per staged row (granules per thread)
+#define MIREG_CORR_BWD_L(WHICH, NTW, NB, gp, fo_, ldo__, dd, lddd, acc_) { \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)correlation_bwd_mfma_kernel<WHICH, NTW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((correlation_bwd_mfma_kernel<WHICH, NTW, NB>), dim3((unsigned)units), dim3(256), lds, stream, (const __bf16*)gp, ldg, \
                            (const __bf16*)fo_, ldo__, (__bf16*)dd, lddd, B, H, W, C, c_norm, R, stride2, acc_, KW, LDB); }
+#define MIREG_CORR_BWD(WHICH, NTW, gp, fo_, ldo__, dd, lddd, acc_) { \
+        if (slots <= 2) MIREG_CORR_BWD_L(WHICH, NTW, 2, gp, fo_, ldo__, dd, lddd, acc_) \
+        else if (slots <= 5) MIREG_CORR_BWD_L(WHICH, NTW, 5, gp, fo_, ldo__, dd, lddd, acc_) \
+        else MIREG_CORR_BWD_L(WHICH, NTW, 14, gp, fo_, ldo__, dd, lddd, acc_) }
       if (df1) { if (ntw <= 1) MIREG_CORR_BWD(0, 1, g, f2, ld2, df1, ldd1, accumulate1) else if (ntw == 2) MIREG_CORR_BWD(0, 2, g, f2, ld2, df1, ldd1, accumulate1) else MIREG_CORR_BWD(0, 4, g, f2, ld2, df1, ldd1, accumulate1) }
       if (df2) { if (ntw <= 1) MIREG_CORR_BWD(1, 1, g, f1, ld1, df2, ldd2, accumulate2) else if (ntw == 2) MIREG_CORR_BWD(1, 2, g, f1, ld1, df2, ldd2, accumulate2) else MIREG_CORR_BWD(1, 4, g, f1, ld1, df2, ldd2, accumulate2) }
 #undef MIREG_CORR_BWD
+#undef MIREG_CORR_BWD_L
       MIREG_LAUNCH_RET();
     }
   }
