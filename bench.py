@@ -291,19 +291,21 @@ def main():
         # kernel is not in it, traffic stays null rather than quoting a stale number.
         try:
             import subprocess
-            prof = os.path.join(ROOT, "profiles", "round2_pmc_conv_kernels.json")
+            prof = os.path.join(ROOT, "profiles", "round3_pmc_conv_kernels.json")
             pmc = json.load(open(prof))
             csrc = os.path.join(ROOT, "self-supervised-medical-image-registration-using-deep-optical-flow-estimation-with-brain-mri-data_amd", "csrc")
             import hashlib
-            hsh = hashlib.sha1(b"".join(open(os.path.join(csrc, f), "rb").read() for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h")))).hexdigest()[:12]
+            # the contraction kernels' sources (what the PMC pass measured): conv_*.hip + the shared header
+            hsh = hashlib.sha1(b"".join(open(os.path.join(csrc, f), "rb").read() for f in sorted(os.listdir(csrc))
+                                        if (f.startswith("conv_") and f.endswith(".hip")) or f == "mireg_common.h")).hexdigest()[:12]
             key = {"conv_wgrad_kernel<128,128>": "conv_wgrad_dma_kernel", "conv_wgrad_halo_kernel": "conv_wgrad_halo"}.get(dom[0], dom[0].split("<")[0])
             ent = next((v for k, v in pmc["kernels"].items() if key in k), None)
             if ent is not None and pmc.get("csrc_sha1") == hsh and args.model == "flownets" and args.batch == 24 and args.size == 256:
                 rd, wr = ent["TCC_EA0_RDREQ_sum"]["mean_per_launch"], ent["TCC_EA0_WRREQ_sum"]["mean_per_launch"]
                 roof["traffic"] = round(2 * rd * 64 + wr * 64)
-                roof["traffic_note"] = f"bytes per launch, mean over the step's launches of {key}, from profiles/round2_pmc_conv_kernels.json (csrc sha1 {hsh})"
+                roof["traffic_note"] = f"bytes per launch, mean over the step's launches of {key}, from profiles/round3_pmc_conv_kernels.json (csrc sha1 {hsh})"
             else:
-                roof["traffic_note"] = (f"null: profiles/round2_pmc_conv_kernels.json was taken on csrc sha1 {pmc.get('csrc_sha1')}, "
+                roof["traffic_note"] = (f"null: profiles/round3_pmc_conv_kernels.json was taken on csrc sha1 {pmc.get('csrc_sha1')}, "
                                         f"this tree is {hsh}" if ent is not None else f"null: {key} not in the committed PMC summary")
         except Exception as e:                                       # noqa: BLE001 -- the bench line must still print
             roof["traffic_note"] = f"null: PMC summary unavailable ({e!r})"

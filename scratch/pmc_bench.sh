@@ -20,6 +20,6 @@ for k, d in agg.items():
     out[k] = {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in d.items()}
     print(k, {c: round(sum(v)/len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
 csrc = os.path.join(os.environ["GRAFT_REPO_ROOT"], "self-supervised-medical-image-registration-using-deep-optical-flow-estimation-with-brain-mri-data_amd", "csrc")
-sha = hashlib.sha1(b"".join(open(os.path.join(csrc, f), "rb").read() for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h")))).hexdigest()[:12]
+sha = hashlib.sha1(b"".join(open(os.path.join(csrc, f), "rb").read() for f in sorted(os.listdir(csrc)) if (f.startswith("conv_") and f.endswith(".hip")) or f == "mireg_common.h")).hexdigest()[:12]
 json.dump({"csrc_sha1": sha, "command": "scratch/pmc_bench.sh (rocprofv3 --pmc over bench.py --no-graph, eager launches)", "kernels": out}, open(sys.argv[3], "w"), indent=1)
 PY
