@@ -555,7 +555,7 @@ def main():
                 opt2.zero_grad()
                 loss.backward()
                 opt2.step()
-                return loss
+                return loss.detach()
             for _ in range(2):
                 f2_train()
             torch.cuda.synchronize()
@@ -567,6 +567,30 @@ def main():
             others["flownet2_train"] = {"pairs_per_s": round(8 / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3), "batch": 8, "loss_total": float(l2.detach()),
                                         "note": "forward + OFEloss + HIP backward of the five sub-networks through torch.autograd + mireg.Adam, eager"}
             log(f"flownet2 train batch 8: {8 / dt2:.1f} pairs/s")
+            try:                                                     # the same step replayed from one hipGraph (the eager form is host-bound)
+                import gc
+                gr2, s2 = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+                s2.wait_stream(torch.cuda.current_stream())
+                gc.disable()
+                try:
+                    with torch.cuda.stream(s2):
+                        with torch.cuda.graph(gr2, stream=s2):
+                            f2_train()
+                finally:
+                    gc.enable()
+                for _ in range(2):
+                    gr2.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    gr2.replay()
+                torch.cuda.synchronize()
+                tg2 = (time.perf_counter() - t0) / 5
+                others["flownet2_train"]["hipgraph"] = {"ms_per_step": round(tg2 * 1e3, 3), "pairs_per_s": round(8 / tg2, 1)}
+                log(f"flownet2 train batch 8, hipGraph replay: {8 / tg2:.1f} pairs/s")
+                del gr2
+            except Exception as e:                                   # noqa: BLE001
+                others["flownet2_train"]["hipgraph"] = {"error": repr(e)}
             del opt2
             del reg2
             torch.cuda.empty_cache()

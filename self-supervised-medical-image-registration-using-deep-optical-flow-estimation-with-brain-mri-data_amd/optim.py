@@ -9,7 +9,7 @@ from typing import Iterable, Optional, Tuple
 import torch
 
 from . import _lib
-from .engine import AdamJob, _stream, upload_table
+from .engine import AdamJob, _stream, upload_table, zero_tensors
 
 
 class Adam:
@@ -55,12 +55,16 @@ class Adam:
         """Default: keep the gradient tensors and zero them (one fill per tensor).  torch.optim's default drops them instead; with
         stable gradient storage the per-step job table of step() never changes (no host-to-device copy after the first step) and the
         whole training step can be captured into a hipGraph.  Pass set_to_none=True for torch's behaviour."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+            return
+        grads = [p.grad for p in self.params if p.grad is not None and p.grad.is_cuda and p.grad.is_contiguous()]
+        for i in range(0, len(grads), 200):                      # one table-driven launch per 200 tensors instead of a fill each
+            zero_tensors(grads[i:i + 200])
         for p in self.params:
-            if p.grad is not None:
-                if set_to_none:
-                    p.grad = None
-                else:
-                    p.grad.zero_()
+            if p.grad is not None and not (p.grad.is_cuda and p.grad.is_contiguous()):
+                p.grad.zero_()
 
     def step(self) -> None:
         jobs, keep = [], []
