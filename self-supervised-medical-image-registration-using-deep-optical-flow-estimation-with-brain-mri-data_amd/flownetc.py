@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib
 from .correlation import correlation_bwd_views, Correlation, correlation_views
 from .engine import BatchNormAct, F32, _stream, lrelu_bwd, nchw_to_view
-from .flownets import (drop_engines, DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block, count_bn_batches,
+from .flownets import (drop_engines, grads_for_autograd, DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block, count_bn_batches,
                        install_bn_counter_hook)
 
 
@@ -195,7 +195,7 @@ class _FlowNetCFn(torch.autograd.Function):
         eng = ctx.eng
         eng.autograd_backward(g if eng.training_cache else (g[0], None, None, None, None))
         table = eng.param_grads()
-        grads = tuple(table[id(p)].clone() if id(p) in table else None for p in ctx.module.parameters())
+        grads = grads_for_autograd(ctx.module.parameters(), table)
         return (None, None) + grads
 
 

@@ -69,6 +69,16 @@ def install_bn_counter_hook(module: nn.Module) -> None:
     module._bn_counter_hook = module.register_state_dict_pre_hook(flush)
 
 
+def grads_for_autograd(params, table: Dict[int, torch.Tensor]) -> tuple:
+    """The engine's persistent gradient buffers as an autograd Function's return value.  A parameter that already has a `.grad`
+    (mireg.Adam.zero_grad keeps and zeroes them) gets the buffer itself: AccumulateGrad adds it in place and keeps no reference, so
+    the per-parameter clone (two extra small kernels per tensor and step, ~1,200 for FlowNet2) is not needed.  Without a `.grad`
+    autograd may adopt the returned tensor as `.grad`, which must then not alias a buffer the next backward overwrites: clone."""
+    return tuple(None if id(p) not in table else
+                 (table[id(p)] if (p.grad is not None and p.grad.data_ptr() != table[id(p)].data_ptr()) else table[id(p)].clone())
+                 for p in params)
+
+
 class PredictorEngineBase:
     """Shared by the predictors: weight packing, gradient unpacking, parameter <-> grad bookkeeping."""
 
@@ -565,7 +575,7 @@ class _FlowNetSFn(torch.autograd.Function):
             g = (gflows[0], gflows[1], None, None, None, None)
         eng.autograd_backward(g)
         table = eng.param_grads()
-        grads = tuple(table[id(p)].clone() if id(p) in table else None for p in ctx.module.parameters())
+        grads = grads_for_autograd(ctx.module.parameters(), table)
         return (None, None) + grads
 
 
