@@ -153,6 +153,9 @@ class FlowNetS3D(nn.Module):
     def fuse_optimizer(self, opt, index: Dict[int, int]) -> None:
         """Every convolution weight but conv1's (whose engine layout is the x-axis im2col of the stem) is updated by `mireg_adam_pack`
         straight from its backward-weights slab; `index` maps id(parameter) to the optimizer's parameter number."""
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise RuntimeError("mireg.Adam(fuse=...) updates the convolution weights from this rank's gradient slabs and leaves no `.grad` "
+                               "for an all-reduce: use it in single-process training only (DistributedDataParallel needs the plain optimizer)")
         self._fopt = opt
         self._fidx = {n: index[id(p)] for n, p in self._named()
                       if p.dim() == 5 and n != "conv1.0.weight" and id(p) in index}

@@ -92,6 +92,31 @@ def test_conv3d_backward_vs_torch(cin, cout, k, stride, vol):
     assert _rel(gb.cpu(), br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("cin,cout,k,stride,pad", [(16, 32, 5, (2, 2, 2), (2, 2, 2)), (70, 12, 3, (1, 1, 1), (1, 1, 1)),
+                                                  (3, 3, 4, (2, 2, 2), (1, 1, 1)), (130, 200, 3, (2, 2, 2), (1, 1, 1)),
+                                                  (8, 16, 7, (2, 2, 1), (3, 3, 0))])
+def test_conv3d_backward_data_packs_from_forward_packs_equal_the_direct_packs(prec, cin, cout, k, stride, pad):
+    """mireg_pack_dgrad3d_fwd (class packs transposed out of the layer's forward pack, round 3) against mireg_pack_dgrad3d (gathered
+    from the fp32 weights): bit-identical class packs, including the zero output-channel padding, for odd channel counts, channel
+    tiles beyond 64 and every stride / padding the volume models use."""
+    from mireg.affine3d import Conv3dLayer
+    from mireg.engine import Workspace, run_pack
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    w = nets.analytic_input((cout, cin, k, k, k if stride[2] > 1 or k < 7 else 1), seed=5, lo=-0.3, hi=0.3).to(DEV)
+    ws = Workspace(torch.device(DEV), dt)
+    lay = Conv3dLayer(w, None, stride, pad, ws)
+    run_pack([lay.pack_job()], ws.code, DEV)
+    Conv3dLayer.pack_dgrad_table([lay], ws)
+    direct = [c["pack"].clone() for c in lay.dgrad_classes()]
+    for c in lay.dgrad_classes():
+        c["pack"].fill_(7.0)
+    Conv3dLayer.pack_dgrad_table([lay], ws, from_fwd=True)
+    torch.cuda.synchronize()
+    for a, c in zip(direct, lay.dgrad_classes()):
+        assert torch.equal(a, c["pack"])
+
+
 def test_affine_sample3d_backward_vs_oracle():
     from mireg import _lib
     from mireg.engine import _stream
