@@ -547,7 +547,7 @@ def main():
             log(f"flownet2 eval batch 8: {8 / dt2:.1f} pairs/s")
             # its training step as the reference runs it (train.py:48-57): forward, OFEloss, autograd backward (HIP per sub-network), Adam
             reg2.train()
-            opt2 = mireg.Adam(reg2.parameters(), 1e-4, eps=1e-4)
+            opt2 = mireg.Adam(reg2.parameters(), 1e-4, eps=1e-4, fuse=reg2)          # convolution weights: packed-domain Adam from the slabs
 
             def f2_train():
                 flows, warped, _, _ = reg2(x2)
@@ -565,7 +565,7 @@ def main():
             torch.cuda.synchronize()
             dt2 = (time.perf_counter() - t0) / 4
             others["flownet2_train"] = {"pairs_per_s": round(8 / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3), "batch": 8, "loss_total": float(l2.detach()),
-                                        "note": "forward + OFEloss + HIP backward of the five sub-networks through torch.autograd + mireg.Adam, eager"}
+                                        "note": "forward + OFEloss + HIP backward of the five sub-networks through torch.autograd + mireg.Adam(fuse=model), eager; hipgraph = the same step replayed from one hipGraph"}
             log(f"flownet2 train batch 8: {8 / dt2:.1f} pairs/s")
             try:                                                     # the same step replayed from one hipGraph (the eager form is host-bound)
                 import gc

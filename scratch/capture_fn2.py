@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 x2, _ = make_pairs(8, 256, seed=3)
 x2 = x2.to(dev)
 reg2 = mireg.opticalFlowReg("flownet2", precision="bf16").to(dev).train()
-opt2 = mireg.Adam(reg2.parameters(), 1e-4, eps=1e-4)
+opt2 = mireg.Adam(reg2.parameters(), 1e-4, eps=1e-4, fuse=None if os.environ.get("NOFUSE") else reg2)
 
 def step():
     flows, warped, _, _ = reg2(x2)

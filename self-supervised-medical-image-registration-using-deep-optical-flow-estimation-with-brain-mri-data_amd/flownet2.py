@@ -21,7 +21,7 @@ import torch.nn as nn
 from .engine import F32, BatchNormAct, lrelu_bwd, nchw_to_view, zero_tensors
 from .flownet2_ops import ChannelNorm, Resample2d, Upsample
 from .flownetc import FlowNetC
-from .flownets import (drop_engines, grads_for_autograd, DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, FlowNetSEngine, PredictorEngineBase, conv_block,
+from .flownets import (drop_engines, grads_for_autograd, PackedOptimizerHook, DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, FlowNetSEngine, PredictorEngineBase, conv_block,
                        count_bn_batches, install_bn_counter_hook)
 
 # (name, cin, cout, stride), all 3x3 -- flownet2/networks/FlowNetSD.py:17-29
@@ -344,14 +344,14 @@ class _StackFn(torch.autograd.Function):
         g = (None,) * ctx.skip + tuple(g)
         if isinstance(eng, FlowNetSEngine):
             g = g + (None,) * (6 - len(g))
-        eng.autograd_backward(g)
+        eng.autograd_backward(g, ctx.module._findex)
         table = eng.param_grads()
         grads = grads_for_autograd(ctx.module.parameters(), table)
         dx = eng.input_grad() if ctx.dx else None
         return (None, None, None, None, None, dx) + grads
 
 
-class _EngineCache:
+class _EngineCache(PackedOptimizerHook):
     """One engine per (input shape, device, precision, parameter storage)."""
 
     def _engine(self, x: torch.Tensor, cls, channels: int):

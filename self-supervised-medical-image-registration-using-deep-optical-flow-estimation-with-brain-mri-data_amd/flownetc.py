@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib
 from .correlation import correlation_bwd_views, Correlation, correlation_views
 from .engine import BatchNormAct, F32, _stream, lrelu_bwd, nchw_to_view
-from .flownets import (drop_engines, grads_for_autograd, DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block, count_bn_batches,
+from .flownets import (drop_engines, grads_for_autograd, PackedOptimizerHook, DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block, count_bn_batches,
                        install_bn_counter_hook)
 
 
@@ -193,13 +193,13 @@ class _FlowNetCFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *g):
         eng = ctx.eng
-        eng.autograd_backward(g if eng.training_cache else (g[0], None, None, None, None))
+        eng.autograd_backward(g if eng.training_cache else (g[0], None, None, None, None), ctx.module._findex)
         table = eng.param_grads()
         grads = grads_for_autograd(ctx.module.parameters(), table)
         return (None, None) + grads
 
 
-class FlowNetC(nn.Module):
+class FlowNetC(nn.Module, PackedOptimizerHook):
     """Drop-in for flownet2.networks.FlowNetC.FlowNetC(args, batchNorm=True, div_flow=20)."""
 
     def __init__(self, args=None, batchNorm: bool = True, div_flow: float = 20, precision: str = "bf16"):

@@ -69,6 +69,29 @@ def install_bn_counter_hook(module: nn.Module) -> None:
     module._bn_counter_hook = module.register_state_dict_pre_hook(flush)
 
 
+class PackedOptimizerHook:
+    """Mixin of the predictor modules (FlowNetS, FlowNetC, PWCDCNet, the FlowNet2 sub-networks): `mireg.Adam(params, fuse=model)`
+    finds every sub-module with `fuse_optimizer` and from then on updates their convolution weights in the packed domain
+    (`PredictorEngineBase.fused_adam`); those weights never get a `.grad`.  Single process, one backward per step."""
+    _fopt = None
+    _findex: Optional[Dict[int, int]] = None
+
+    def fuse_optimizer(self, opt, index: Dict[int, int]) -> None:
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise RuntimeError("mireg.Adam(fuse=...) updates the convolution weights from this rank's gradient slabs and leaves no `.grad` "
+                               "for an all-reduce: single-process training only (RegistrationTrainer is the data-parallel path)")
+        self._fopt, self._findex = opt, index
+
+    def fused_pending(self) -> bool:
+        return any(e.slab_pending for e in getattr(self, "_engines", {}).values())
+
+    def fused_step(self, opt, tick: int) -> None:
+        for e in getattr(self, "_engines", {}).values():
+            if e.slab_pending:
+                e.fused_adam(opt, tick)
+                tick = 0
+
+
 def grads_for_autograd(params, table: Dict[int, torch.Tensor]) -> tuple:
     """The engine's persistent gradient buffers as an autograd Function's return value.  A parameter that already has a `.grad`
     (mireg.Adam.zero_grad keeps and zeroes them) gets the buffer itself: AccumulateGrad adds it in place and keeps no reference, so
@@ -104,6 +127,10 @@ class PredictorEngineBase:
     # wgrad(L) and dgrad(L) are independent and each alone under-fills 256 CUs on the deep layers, so wgrad is
     # forked onto a second HIP stream (captured as a parallel hipGraph branch) and joined before the unpack.
     use_side_stream = True
+    # packed-domain optimizer under torch.autograd (mireg.Adam(fuse=model), PackedOptimizerHook below)
+    fused_index: Optional[Dict[int, int]] = None
+    slab_pending = False
+    _fresh = None
 
     def mark(self):
         """Event on the current stream: 'the operands of a later wgrad_async(..., after=ev) are ready here'."""
@@ -156,6 +183,10 @@ class PredictorEngineBase:
         """torch-layout fp32 parameters -> GEMM packs (one table-driven launch)."""
         if self.packs_fresh and not force and not dgrad_only:
             return
+        if self._fresh is not None and not force and not dgrad_only:      # fused_adam rewrote F and D packs with the new weights
+            fresh, self._fresh = self._fresh, None
+            if all(p._version == v for p, v in fresh):                    # ... and nobody has written a parameter since
+                return
         key = tuple(l.weight.data_ptr() for l in self.layers.values())
         if self._pack_key != key:
             jobs = [j for l in self.layers.values() for j in l.pack_jobs()]
@@ -170,6 +201,8 @@ class PredictorEngineBase:
         """wgrad slabs -> torch-layout gradients, for all layers or for the named subset (one backward phase)."""
         if self.grad_mode == "packed":
             return self.reduce_grads(names)
+        if self.fused_index is not None:                       # the weights are updated straight from the slabs by fused_adam()
+            return
         key = tuple(names) if names is not None else None
         if self._unpack_table is None:
             self._unpack_table = {}
@@ -287,13 +320,61 @@ class PredictorEngineBase:
             b.grad_g, b.grad_b = view(b.bn.weight), view(b.bn.bias)
         self._unpack_table = None
 
-    def autograd_backward(self, g) -> None:
-        """backward() ending in torch-layout gradients even when a trainer has bound this engine to the packed domain."""
-        mode, self.grad_mode = self.grad_mode, "torch"
+    def autograd_backward(self, g, fused: Optional[Dict[int, int]] = None) -> None:
+        """backward() ending in torch-layout gradients even when a trainer has bound this engine to the packed domain.
+        fused = {id(parameter): optimizer index} of a mireg.Adam(fuse=...): the convolution weights' gradients then stay in their
+        backward-weights slabs (no unpack; `param_grads()` has no entry for them) until `fused_adam` consumes them."""
+        if fused is not None and self.slab_pending:
+            raise RuntimeError("a second backward before optimizer.step(): with mireg.Adam(fuse=...) the weight gradients live in the "
+                               "backward-weights slabs, which one backward fills and one step consumes")
+        mode, self.grad_mode, self.fused_index = self.grad_mode, "torch", fused
         try:
             self.backward(g)
+            self.slab_pending = fused is not None
         finally:
             self.grad_mode = mode
+        if fused is not None:                                  # torch-layout weight gradients are not produced in this mode
+            for l in self.layers.values():
+                if id(l.weight) in fused:
+                    l.grad_w = None
+
+    def fused_adam(self, opt, tick: int) -> None:
+        """Slabs -> (in-place slab sum) -> Adam on the fp32 master weights + refreshed forward packs (`mireg_adam_pack`), then the
+        backward-data packs from the fresh forward packs: the 2-D trainer's packed-domain optimizer for a model that trains through
+        torch.autograd.  Biases and BatchNorm parameters keep the ordinary `.grad` / `mireg_adam_step` path."""
+        index, st = self.fused_index, _stream()
+        red, jobs, r, units, max_taps, done = [], [], 0, 0, 1, []
+        for l in self.layers.values():
+            if l.wgrad_slab is None or id(l.weight) not in index:
+                continue
+            ns = l.wgrad_split * l.n_slots
+            j = WoptJob()
+            j.slab = j.g = l.wgrad_slab.data_ptr()
+            j.slab_stride, j.nsplit = l.Co * l.Kf, ns
+            j.Co, j.Ci, j.taps, j.Cpad, j.ld = l.Co, l.Ci, l.kh * l.kw, l.Cip, l.Kf
+            j.p, j.F = l.weight.data_ptr(), l.packF.data_ptr()
+            j.m, j.v = opt.state_ptrs(index[id(l.weight)])
+            j.unit0, j.runit0 = units, r
+            units += l.Co * ((l.Cip + 63) // 64)
+            max_taps = max(max_taps, l.kh * l.kw)
+            jobs.append(j)
+            done.append(l.weight)
+            if ns > 1:
+                red.append(WoptJob.from_buffer_copy(j))
+                r += (l.Co * l.Kf + 255) // 256
+        self.slab_pending = False
+        if not jobs:
+            return
+        if red:
+            self._ftab_r = upload_table(red, self.ws.device)
+            _lib.call("mireg_wgrad_reduce", self._ftab_r.data_ptr(), len(red), r, st)
+        self._ftab = upload_table(jobs, self.ws.device)
+        _lib.call("mireg_adam_pack", self._ftab.data_ptr(), len(jobs), units, max_taps, opt.step_dev.data_ptr(), int(tick), opt.lr,
+                  opt.betas[0], opt.betas[1], opt.eps, 1.0, self.ws.code, st)
+        self.pack_weights(dgrad_only=True)
+        # forward and backward-data packs are current for the next forward if every packed layer was just rewritten
+        every = all(l.wgrad_slab is not None and id(l.weight) in index for l in self.layers.values())
+        self._fresh = [(w, w._version) for w in done] if every else None
 
     def param_grads(self) -> Dict[int, torch.Tensor]:
         """id(parameter) -> persistent fp32 gradient buffer (torch layout)."""
@@ -573,13 +654,13 @@ class _FlowNetSFn(torch.autograd.Function):
             g = gflows
         else:  # eval arity (flow0, flow2)
             g = (gflows[0], gflows[1], None, None, None, None)
-        eng.autograd_backward(g)
+        eng.autograd_backward(g, ctx.module._findex)
         table = eng.param_grads()
         grads = grads_for_autograd(ctx.module.parameters(), table)
         return (None, None) + grads
 
 
-class FlowNetS(nn.Module):
+class FlowNetS(nn.Module, PackedOptimizerHook):
     """Drop-in for reference FlowNetS.FlowNetS.FlowNetS (constructor `batchNorm=True`).
 
     precision: "bf16" (bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the throughput

@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import _lib
 from .correlation import Correlation, WarpBwdWorkspace, correlation_bwd_views, correlation_views, pwc_warp_bwd_views, pwc_warp_views
 from .engine import F32, View, _stream, cast_from_f32, lrelu_bwd, nchw_to_view, zero_many_table, zero_tensors
-from .flownets import drop_engines, grads_for_autograd, PredictorEngineBase
+from .flownets import drop_engines, grads_for_autograd, PackedOptimizerHook, PredictorEngineBase
 
 SLOPE = 0.1
 PYRAMID = [(1, 16), (16, 32), (32, 64), (64, 96), (96, 128), (128, 196)]      # PWCNet.py:50-67
@@ -281,13 +281,13 @@ class _PWCFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *g):
-        ctx.eng.autograd_backward(g)
+        ctx.eng.autograd_backward(g, ctx.module._findex)
         table = ctx.eng.param_grads()
         grads = grads_for_autograd(ctx.module.parameters(), table)
         return (None, None) + grads
 
 
-class PWCDCNet(nn.Module):
+class PWCDCNet(nn.Module, PackedOptimizerHook):
     """Drop-in for PWC.models.PWCNet.PWCDCNet(md=4)."""
 
     def __init__(self, md: int = 4, precision: str = "bf16"):

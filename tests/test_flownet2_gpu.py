@@ -181,3 +181,52 @@ def test_flownet2_trains_end_to_end():
         report[sub] = (rel, noise)
         assert rel <= 5e-3 + 8 * noise, (sub, rel, noise)
     print("FlowNet2 end-to-end gradient rel L2 vs fp64 oracle per sub-network (HIP, oracle-fp32 noise):", report)
+
+
+@pytest.mark.parametrize("name", ["flownets", "flownetc", "pwc", "flownet2"])
+def test_packed_domain_adam_under_autograd_matches_the_plain_optimizer(name):
+    """mireg.Adam(fuse=model) for the models that train through torch.autograd (round 3): convolution weights updated from their
+    backward-weights slabs by `mireg_adam_pack` (no gradient unpack, no re-pack; no `.grad` on those weights), everything else through
+    `.grad` / `mireg_adam_step`.  Four steps of both optimizers from the same seed: same losses, same parameters, and the forward
+    after the last step (which runs on the packs the optimizer rewrote) gives the same flows."""
+    import mireg
+    from mireg.synth import make_pairs
+    x, _ = make_pairs(2, 128 if name != "flownet2" else 256, seed=4)
+    x = x.to(DEV)
+
+    def build(fuse):
+        torch.manual_seed(11)
+        m = mireg.opticalFlowReg(name, precision="fp32").to(DEV).train()
+        return m, mireg.Adam(m.parameters(), 1e-4, eps=1e-4, fuse=m if fuse else None)
+
+    def step(m, opt):
+        flows, warped, _, _ = m(x)
+        loss = mireg.OFEloss(flows, warped, x[:, 0:1])[3]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    (ma, oa), (mb, ob) = build(False), build(True)
+    for _ in range(4):
+        la, lb = step(ma, oa), step(mb, ob)
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)), (float(la), float(lb))
+    torch.cuda.synchronize()
+    fused_any = False
+    for (k, a), (_, b) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.isfinite(b).all(), k
+        assert (a - b).abs().max().item() <= 1e-6 + 2e-5 * a.abs().max().item(), k
+        if b.dim() == 4 and b.grad is None and a.grad is not None:
+            fused_any = True
+    assert fused_any
+    ma.eval(), mb.eval()
+    with torch.no_grad():
+        fa, fb = ma(x)[0][0], mb(x)[0][0]
+    assert (fa - fb).abs().max().item() <= 1e-5 + 1e-4 * fa.abs().max().item()
+    # one backward per step
+    mb.train()
+    flows, warped, _, _ = mb(x)
+    mireg.OFEloss(flows, warped, x[:, 0:1])[3].backward()
+    flows, warped, _, _ = mb(x)
+    with pytest.raises(RuntimeError, match="second backward"):
+        mireg.OFEloss(flows, warped, x[:, 0:1])[3].backward()
