@@ -588,7 +588,9 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
         self.grads_ready = True
 
     DEC_LAYERS = [f"deconv{l}" for l in DECONV] + [f"predict_flow{l}" for l in PREDICT] + [f"up{l}" for l in (6, 5, 4, 3)]
-    PHASE_ENC = (("conv6_1", "conv6", "conv5_1", "conv5"), ("conv4_1", "conv4", "conv3_1", "conv3", "conv2", "conv1"))
+    # (measured, round 3: a third encoder phase -- conv4_1 conv4 conv3_1 | conv3 conv2 conv1, so that less optimizer work stays exposed
+    # after the backward's last kernel -- is 1-2 % SLOWER: every phase boundary is a join of the backward-weights stream)
+    PHASE_ENC = tuple(tuple(t.split()) for t in os.environ.get("MIREG_PHASE_ENC", "conv6_1 conv6 conv5_1 conv5|conv4_1 conv4 conv3_1 conv3 conv2 conv1").split("|"))
 
     def backward_phases(self, gflows: Sequence[Optional[torch.Tensor]]):
         """The backward pass cut where gradient buckets complete: decoder | conv6_1..conv5 | conv4_1..conv1.
@@ -613,17 +615,16 @@ class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
                     self.join_side()
                     self.unpack_grads(names)
             return run
-        return [decoder, encoder(self.PHASE_ENC[0]), encoder(self.PHASE_ENC[1])]
+        return [decoder] + [encoder(names) for names in self.PHASE_ENC]
 
     def phase_layers(self):
         """(layer names, BatchNorm names) of every backward phase, in phase order."""
         bn = lambda names: tuple(names) if self.bn else ()
-        return [(tuple(self.DEC_LAYERS), ()), (self.PHASE_ENC[0], bn(self.PHASE_ENC[0])), (self.PHASE_ENC[1], bn(self.PHASE_ENC[1]))]
+        return [(tuple(self.DEC_LAYERS), ())] + [(names, bn(names)) for names in self.PHASE_ENC]
 
     def phase_ranges(self) -> List[Tuple[int, int]]:
         bn = lambda names: names if self.bn else ()
-        return [self.flat_range(self.DEC_LAYERS), self.flat_range(self.PHASE_ENC[0], bn(self.PHASE_ENC[0])),
-                self.flat_range(self.PHASE_ENC[1], bn(self.PHASE_ENC[1]))]
+        return [self.flat_range(self.DEC_LAYERS)] + [self.flat_range(names, bn(names)) for names in self.PHASE_ENC]
 
     def input_grad(self) -> torch.Tensor:
         """d loss / d x as (B, cin, H, W) fp32 (only with `want_dx`, set before the first backward)."""
