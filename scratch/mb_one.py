@@ -1,4 +1,4 @@
-"""One contraction shape, a fixed number of launches of the ring kernel and of the halo kernel (for rocprofv3 --pmc runs):
+"""One contraction shape, a fixed number of launches of the ring kernel, the halo kernel and the 8-wave tile (for rocprofv3 --pmc runs):
 python3 scratch/mb_one.py [cin cout k s H form]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +18,7 @@ x = ws.new(B, H, H, cin); x.buf.normal_()
 y = ws.new(B, Ho, Ho, cout); y.buf.normal_()
 dx = ws.new(B, H, H, cin)
 run = (lambda: lay.run_fwd_form(x, y)) if form == "fwd" else (lambda: lay.run_dgrad_form(y, dx))
-for force in ((1, 0), (2, 128), (2, 256)):
+for force in ((1, 0), (2, 128), (2, 256), (3, 256, 128), (3, 256, 256)):      # ring, halo 128 / 256 rows, 8-wave tile 128 / 256 columns
     engine.FORCE_ALGO = force
     try:
         for _ in range(12):
