@@ -131,6 +131,17 @@ int mireg_smoothness3d_fwd(const float* flow, long fsb, long fsc, long fsp, doub
                            hipStream_t stream);
 int mireg_smoothness3d_bwd(const float* flow, long fsb, long fsc, long fsp, const float* coef, float* gflow, float beta, int B,
                            int d, int h, int w, hipStream_t stream);
+/* ---- the 3 -> 3 channel flow upsamplers of the volume predictor, ConvTranspose3d(3, 3, 4, 2, 1) (FlowNetS/FlowNetS.py:37-40 per axis; + autograd),
+ * one thread per voxel on the fp32 weight w = [3 coarse][3 fine][4][4][4] (the ConvTranspose3d parameter as stored).  x_coarse / dx_coarse:
+ * (B, Dc, Hc, Wc, ld_c) channel-last; y_fine / g_fine: (B, 2Dc, 2Hc, 2Wc, ld_f); three channels used.  bwd_weights writes nblocks =
+ * mireg_tiny_deconv3d_blocks(...) partial slabs [nblocks][3][64 * Cpad] in the standard backward-weights layout (summed by mireg_wgrad_reduce). */
+int mireg_tiny_deconv3d_blocks(int B, int Dc, int Hc, int Wc);
+int mireg_tiny_deconv3d_fwd(const void* x_coarse, long ld_c, const float* w, void* y_fine, long ld_f, int B, int Dc, int Hc, int Wc,
+                            int dtype, hipStream_t stream);
+int mireg_tiny_deconv3d_bwd_data(const void* g_fine, long ld_f, const float* w, void* dx_coarse, long ld_c, int accumulate, int B, int Dc,
+                                 int Hc, int Wc, int dtype, hipStream_t stream);
+int mireg_tiny_deconv3d_bwd_weights(const void* g_fine, long ld_f, const void* x_coarse, long ld_c, float* slab, int nblocks, int Cpad, int B,
+                                    int Dc, int Hc, int Wc, int dtype, hipStream_t stream);
 /* x-axis im2col of a few-channel planar fp32 volume (the 7^3 / stride-2 / 2-channel input convolution of FlowNetS over
  * volumes, the 3-D counterpart of FlowNetS/FlowNetS.py:18): dst[b][z][y][xo][tx*C + c] = x[b][c][z][y][xo*stride + tx - pad]
  * (zeros outside and in the pad channels), dst channel-last with Cpad >= k*C channels (a multiple of 8), Wo = (W + 2*pad - k)/stride + 1.

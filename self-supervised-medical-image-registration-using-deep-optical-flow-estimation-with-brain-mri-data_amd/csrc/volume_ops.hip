@@ -345,6 +345,113 @@ stem3d_gather_kernel(const float* __restrict__ x, T* __restrict__ dst, int B, in
   }
 }
 
+// ---- the 3 -> 3 channel flow upsamplers of FlowNetS over volumes, ConvTranspose3d(3, 3, 4, 2, 1) (FlowNetS/FlowNetS.py:37-40 per axis) -----------
+// A few MFLOP each; through the 128-wide GEMM tiles they were 8 parity-class launches forward, 1 backward-data and 4 backward-weights launches per
+// level (56 launches, ~0.9 ms per step).  Here: one thread per voxel on the fp32 master weight Wc[co][ci][tz][ty][tx] (the Conv3d weight of the
+// adjoint, stride-2 convolution fine(ci) -> coarse(co); 576 floats), as the 2-D tiny_* kernels of thin_conv.hip do for 2 -> 2 channels.
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+tiny_deconv3d_fwd_kernel(const T* __restrict__ xc, long ld_c, const float* __restrict__ w, T* __restrict__ yf, long ld_f, int B, int Dc, int Hc,
+                         int Wc, Vox step) {
+  const int Df = 2 * Dc, Hf = 2 * Hc, Wf = 2 * Wc;
+  const long n = (long)B * Df * Hf * Wf;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Vox q = vox_split(i, Wf, Hf, Df);
+  for (; i < n; i += (long)gridDim.x * blockDim.x, vox_advance(q, step, Wf, Hf, Df)) {
+    float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tz = 0; tz < 2; ++tz) {
+      const int kz = ((q.z + 1) & 1) + 2 * tz, oz = (q.z + 1 - kz) >> 1;           // fine slice z receives taps kz = (z + 1) mod 2, + 2
+      if ((unsigned)oz >= (unsigned)Dc) continue;
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty) {
+        const int ky = ((q.y + 1) & 1) + 2 * ty, oy = (q.y + 1 - ky) >> 1;
+        if ((unsigned)oy >= (unsigned)Hc) continue;
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+          const int kx = ((q.x + 1) & 1) + 2 * tx, ox = (q.x + 1 - kx) >> 1;
+          if ((unsigned)ox >= (unsigned)Wc) continue;
+          const T* src = xc + ((((long)q.p * Dc + oz) * Hc + oy) * Wc + ox) * ld_c;
+          const int t = (kz * 4 + ky) * 4 + kx;
+#pragma unroll
+          for (int co = 0; co < 3; ++co) {
+            const float c = (float)src[co];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) a[ci] += c * w[(co * 3 + ci) * 64 + t];
+          }
+        }
+      }
+    }
+    T* d = yf + i * ld_f;
+    d[0] = (T)a[0]; d[1] = (T)a[1]; d[2] = (T)a[2];
+  }
+}
+
+// backward-data of the upsampler = the stride-2 convolution itself: coarse[o][co] (+)= sum_{ci, k} fine[2 o + k - 1][ci] * Wc[co][ci][k]
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+tiny_conv3d_fwd_kernel(const T* __restrict__ xf, long ld_f, const float* __restrict__ w, T* __restrict__ yc, long ld_c, int accumulate, int B,
+                       int Dc, int Hc, int Wc, Vox step) {
+  const int Df = 2 * Dc, Hf = 2 * Hc, Wf = 2 * Wc;
+  const long n = (long)B * Dc * Hc * Wc;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Vox q = vox_split(i, Wc, Hc, Dc);
+  for (; i < n; i += (long)gridDim.x * blockDim.x, vox_advance(q, step, Wc, Hc, Dc)) {
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int kz = 0; kz < 4; ++kz) {
+      const int iz = 2 * q.z + kz - 1;
+      if ((unsigned)iz >= (unsigned)Df) continue;
+      for (int ky = 0; ky < 4; ++ky) {
+        const int iy = 2 * q.y + ky - 1;
+        if ((unsigned)iy >= (unsigned)Hf) continue;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          const int ix = 2 * q.x + kx - 1;
+          if ((unsigned)ix >= (unsigned)Wf) continue;
+          const T* src = xf + ((((long)q.p * Df + iz) * Hf + iy) * Wf + ix) * ld_f;
+          const int t = (kz * 4 + ky) * 4 + kx;
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci) {
+            const float f = (float)src[ci];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) a[co] += f * w[(co * 3 + ci) * 64 + t];
+          }
+        }
+      }
+    }
+    T* d = yc + i * ld_c;
+#pragma unroll
+    for (int co = 0; co < 3; ++co) d[co] = (T)(accumulate ? (float)d[co] + a[co] : a[co]);
+  }
+}
+
+// backward-weights: block = a contiguous chunk of coarse voxels, thread = (tap, fine channel ci), three accumulators (co); partial slab
+// [block][co][tap * Cpad + ci] in the layers' standard slab layout (summed by mireg_wgrad_reduce in fixed order: run-to-run identical)
+constexpr int kTinyW3Threads = 192;
+template <typename T>
+__global__ void __launch_bounds__(kTinyW3Threads)
+tiny_wgrad3d_kernel(const T* __restrict__ gf, long ld_f, const T* __restrict__ xc, long ld_c, float* __restrict__ slab, int Cpad, int B,
+                    int Dc, int Hc, int Wc, int per_block) {
+  const int Df = 2 * Dc, Hf = 2 * Hc, Wf = 2 * Wc;
+  const long n = (long)B * Dc * Hc * Wc;
+  const int t = threadIdx.x / 3, ci = threadIdx.x - 3 * t;
+  const int kz = t >> 4, ky = (t >> 2) & 3, kx = t & 3;
+  float a[3] = {0.f, 0.f, 0.f};
+  const long v0 = (long)blockIdx.x * per_block, v1 = v0 + per_block < n ? v0 + per_block : n;
+  Vox q = vox_split(v0, Wc, Hc, Dc);
+  const Vox one = {1, 0, 0, 0};
+  for (long v = v0; v < v1; ++v, vox_advance(q, one, Wc, Hc, Dc)) {
+    const int iz = 2 * q.z + kz - 1, iy = 2 * q.y + ky - 1, ix = 2 * q.x + kx - 1;
+    if ((unsigned)iz >= (unsigned)Df || (unsigned)iy >= (unsigned)Hf || (unsigned)ix >= (unsigned)Wf) continue;
+    const float f = (float)gf[((((long)q.p * Df + iz) * Hf + iy) * Wf + ix) * ld_f + ci];
+    const T* c = xc + v * ld_c;
+    a[0] += f * (float)c[0]; a[1] += f * (float)c[1]; a[2] += f * (float)c[2];
+  }
+  float* d = slab + (long)blockIdx.x * 3 * 64 * Cpad + (long)t * Cpad + ci;
+#pragma unroll
+  for (int co = 0; co < 3; ++co) d[(long)co * 64 * Cpad] = a[co];
+}
+
 }  // namespace
 
 extern "C" {
@@ -441,5 +548,51 @@ int mireg_stem3d_gather(const float* x, void* dst, int B, int C, int D, int H, i
                        reinterpret_cast<float*>(dst), B, C, D, H, W, Wo, k, stride, pad, Cpad, step);
   MIREG_LAUNCH_RET();
 }
+
+int mireg_tiny_deconv3d_blocks(int B, int Dc, int Hc, int Wc) {
+  const long n = (long)B * Dc * Hc * Wc;
+  const long g = (n + 63) / 64;
+  return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+}
+
+int mireg_tiny_deconv3d_fwd(const void* x_coarse, long ld_c, const float* w, void* y_fine, long ld_f, int B, int Dc, int Hc, int Wc,
+                            int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(x_coarse && w && y_fine && ld_c >= 3 && ld_f >= 3 && B > 0 && Dc > 0 && Hc > 0 && Wc > 0);
+  MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
+  const int g = grid_for((long)B * Dc * Hc * Wc * 8);
+  const Vox step = vox_step((long)g * kThreads, 2 * Wc, 2 * Hc, 2 * Dc);
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((tiny_deconv3d_fwd_kernel<__bf16>), dim3(g), dim3(kThreads), 0, stream, (const __bf16*)x_coarse, ld_c, w, (__bf16*)y_fine, ld_f, B, Dc, Hc, Wc, step);
+  else
+    hipLaunchKernelGGL((tiny_deconv3d_fwd_kernel<float>), dim3(g), dim3(kThreads), 0, stream, (const float*)x_coarse, ld_c, w, (float*)y_fine, ld_f, B, Dc, Hc, Wc, step);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_tiny_deconv3d_bwd_data(const void* g_fine, long ld_f, const float* w, void* dx_coarse, long ld_c, int accumulate, int B, int Dc,
+                                 int Hc, int Wc, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(g_fine && w && dx_coarse && ld_c >= 3 && ld_f >= 3 && B > 0 && Dc > 0 && Hc > 0 && Wc > 0);
+  MIREG_CHECK_ARG(dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32);
+  const int g = grid_for((long)B * Dc * Hc * Wc);
+  const Vox step = vox_step((long)g * kThreads, Wc, Hc, Dc);
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((tiny_conv3d_fwd_kernel<__bf16>), dim3(g), dim3(kThreads), 0, stream, (const __bf16*)g_fine, ld_f, w, (__bf16*)dx_coarse, ld_c, accumulate, B, Dc, Hc, Wc, step);
+  else
+    hipLaunchKernelGGL((tiny_conv3d_fwd_kernel<float>), dim3(g), dim3(kThreads), 0, stream, (const float*)g_fine, ld_f, w, (float*)dx_coarse, ld_c, accumulate, B, Dc, Hc, Wc, step);
+  MIREG_LAUNCH_RET();
+}
+
+int mireg_tiny_deconv3d_bwd_weights(const void* g_fine, long ld_f, const void* x_coarse, long ld_c, float* slab, int nblocks, int Cpad, int B,
+                                    int Dc, int Hc, int Wc, int dtype, hipStream_t stream) {
+  MIREG_CHECK_ARG(g_fine && x_coarse && slab && ld_c >= 3 && ld_f >= 3 && B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Cpad >= 3);
+  MIREG_CHECK_ARG(nblocks == mireg_tiny_deconv3d_blocks(B, Dc, Hc, Wc) && (dtype == MIREG_DTYPE_BF16 || dtype == MIREG_DTYPE_F32));
+  const long n = (long)B * Dc * Hc * Wc;
+  const int per = (int)((n + nblocks - 1) / nblocks);
+  if (dtype == MIREG_DTYPE_BF16)
+    hipLaunchKernelGGL((tiny_wgrad3d_kernel<__bf16>), dim3(nblocks), dim3(kTinyW3Threads), 0, stream, (const __bf16*)g_fine, ld_f, (const __bf16*)x_coarse, ld_c, slab, Cpad, B, Dc, Hc, Wc, per);
+  else
+    hipLaunchKernelGGL((tiny_wgrad3d_kernel<float>), dim3(nblocks), dim3(kTinyW3Threads), 0, stream, (const float*)g_fine, ld_f, (const float*)x_coarse, ld_c, slab, Cpad, B, Dc, Hc, Wc, per);
+  MIREG_LAUNCH_RET();
+}
+
 
 }  // extern "C"

@@ -21,6 +21,7 @@ from .engine import BatchNormAct, WoptJob, Workspace, _stream, assign_tiles, rup
 from .volume import resize_trilinear, stn3d
 
 WGRAD_SIDE_STREAM = os.environ.get("MIREG_3D_WGRAD_MAIN", "0") != "1"
+TINY_UPSAMPLERS = os.environ.get("MIREG_3D_GEMM_UPSAMPLERS", "0") != "1"      # A/B switch: the flow upsamplers on the GEMM path
 
 ENC = [("conv1", 7, 2), ("conv2", 5, 2), ("conv3", 5, 2), ("conv3_1", 3, 1), ("conv4", 3, 2), ("conv4_1", 3, 1),
        ("conv5", 3, 2), ("conv5_1", 3, 1), ("conv6", 3, 2), ("conv6_1", 3, 1)]
@@ -139,6 +140,15 @@ class FlowNetS3D(nn.Module):
         return list(self.named_parameters())
 
     @staticmethod
+    def _up_forward(up, coarse: Vol, cdims, fine: Vol, fdims, ws: Workspace) -> None:
+        """The 3 -> 3 channel ConvTranspose3d flow upsampler: one voxel-parallel launch (`mireg_tiny_deconv3d_fwd`) instead of eight
+        parity-class GEMM launches that fill 3 of 128 tile columns."""
+        if TINY_UPSAMPLERS:
+            _lib.call("mireg_tiny_deconv3d_fwd", coarse.ptr, coarse.ld, up.weight.data_ptr(), fine.ptr, fine.ld, coarse.B, *cdims, ws.code, _stream())
+        else:
+            up.dgrad(coarse, cdims, fine, fdims)
+
+    @staticmethod
     def _conv_of(L: dict) -> dict:
         """parameter name -> engine layer of every convolution weight."""
         conv_of = {f"{name}.0.weight": L[name] for name, _, _ in ENC}
@@ -241,7 +251,7 @@ class FlowNetS3D(nn.Module):
             skipc = nxt.C - 3 - dm                                                   # channels of the encoder skip in the next concat
             # deconv (LeakyReLU 0.1) and the flow upsampler are backward-data-form launches into their concat slices
             L[f"deconv{lv - 1}"].dgrad(feat, dims[lv], nxt.slice(skipc, dm), dims[lv - 1], slope=0.1)
-            L[f"up{lv - 1}"].dgrad(e["flow"][lv], dims[lv], nxt.slice(skipc + dm, 3), dims[lv - 1])
+            self._up_forward(L[f"up{lv - 1}"], e["flow"][lv], dims[lv], nxt.slice(skipc + dm, 3), dims[lv - 1], ws)
             feat = nxt
         self._last = dict(e=e, B=B) if keep else None
         # logical (B, 3, d, h, w) views of the channel-last fp32 flows (valid until the next forward of this module)
@@ -299,8 +309,18 @@ class FlowNetS3D(nn.Module):
             below = cat[lv + 1] if lv + 1 < 6 else act["conv6_1"]
             gbelow = gcat[lv + 1] if lv + 1 < 6 else gact["conv6_1"]
             # flow upsampler (ConvTranspose3d 3 -> 3): d/d flow_{lv+1} adds to its loss gradient; weight gradient
-            up.run(gup, dims[lv], e["gflow"][lv + 1], 1.0, accumulate=True)
-            wgrad(up, gup, dims[lv], e["flow"][lv + 1], dims[lv + 1])
+            if TINY_UPSAMPLERS:                                                    # voxel-parallel kernels (csrc/volume_ops.hip), main stream
+                gc_ = e["gflow"][lv + 1]
+                _lib.call("mireg_tiny_deconv3d_bwd_data", gup.ptr, gup.ld, up.weight.data_ptr(), gc_.ptr, gc_.ld, 1, B, *dims[lv + 1], ws.code, st)
+                nb = _lib.lib().mireg_tiny_deconv3d_blocks(B, *dims[lv + 1])
+                if getattr(up, "slab", None) is None or up.slab.shape[0] != nb:
+                    up.slab = torch.zeros(nb, up.Co, up.Kf, device=dev, dtype=torch.float32)
+                fc = e["flow"][lv + 1]
+                _lib.call("mireg_tiny_deconv3d_bwd_weights", gup.ptr, gup.ld, fc.ptr, fc.ld, up.slab.data_ptr(), nb, up.Cip, B, *dims[lv + 1],
+                          ws.code, st)
+            else:
+                up.run(gup, dims[lv], e["gflow"][lv + 1], 1.0, accumulate=True)
+                wgrad(up, gup, dims[lv], e["flow"][lv + 1], dims[lv + 1])
             # deconv: LeakyReLU mask, then backward-data (conv form of the adjoint) opens the gradient of the level below
             mask(gdec, feat.slice(skipc, dm), 0.1)
             dec.run(gdec, dims[lv], gbelow, 1.0)
