@@ -388,3 +388,40 @@ def test_flownets3d_packed_domain_adam_matches_the_plain_optimizer(precision):
     flows, warped = mb(x)
     with pytest.raises(RuntimeError, match="second backward"):
         mireg.OFEloss3d(flows, warped, x[:, 0:1])[3].backward()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("dims", [(2, 3, 4), (4, 4, 4), (1, 1, 1)])
+def test_tiny_deconv3d_kernels_vs_torch_conv_transpose3d(prec, dims):
+    """The voxel-parallel 3 -> 3 channel ConvTranspose3d(4, 2, 1) kernels (flow upsamplers of FlowNetS over volumes): forward,
+    backward-data (accumulating) and backward-weights (partial slabs summed on the host here) against torch on the CPU."""
+    import torch.nn.functional as F
+    from mireg import _lib
+    from mireg.engine import DT_BF16, DT_F32
+    dt, code, tol = (torch.float32, DT_F32, 2e-5) if prec == "fp32" else (torch.bfloat16, DT_BF16, 2e-2)
+    B, (Dc, Hc, Wc) = 2, dims
+    g = torch.Generator().manual_seed(12)
+    w = (torch.rand(3, 3, 4, 4, 4, generator=g) - 0.5)
+    xc = (torch.rand(B, 3, Dc, Hc, Wc, generator=g) - 0.5).to(dt).float()
+    gf = (torch.rand(B, 3, 2 * Dc, 2 * Hc, 2 * Wc, generator=g) - 0.5).to(dt).float()
+    xr, wr = xc.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv_transpose3d(xr, wr, None, 2, 1)
+    y.backward(gf)
+    st = torch.cuda.current_stream().cuda_stream
+    cl = lambda t, ld: torch.nn.functional.pad(t.permute(0, 2, 3, 4, 1), (0, ld - 3)).contiguous().to(DEV).to(dt)
+    xd, gd, wd = cl(xc, 8), cl(gf, 16), w.to(DEV)
+    yd = torch.full((B, 2 * Dc, 2 * Hc, 2 * Wc, 16), 7.0, device=DEV, dtype=dt)
+    _lib.call("mireg_tiny_deconv3d_fwd", xd.data_ptr(), 8, wd.data_ptr(), yd.data_ptr(), 16, B, Dc, Hc, Wc, code, st)
+    got = yd[..., :3].float().cpu().permute(0, 4, 1, 2, 3)
+    assert (got - y.detach()).abs().max().item() <= tol * max(1.0, y.abs().max().item())
+    assert (yd[..., 3:] == 7.0).all()                                        # neighbours in the concat buffer untouched
+    dx = torch.ones(B, Dc, Hc, Wc, 8, device=DEV, dtype=dt)
+    _lib.call("mireg_tiny_deconv3d_bwd_data", gd.data_ptr(), 16, wd.data_ptr(), dx.data_ptr(), 8, 1, B, Dc, Hc, Wc, code, st)
+    got = dx[..., :3].float().cpu().permute(0, 4, 1, 2, 3) - 1.0
+    assert (got - xr.grad).abs().max().item() <= tol * max(1.0, xr.grad.abs().max().item())
+    nb = _lib.lib().mireg_tiny_deconv3d_blocks(B, Dc, Hc, Wc)
+    slab = torch.zeros(nb, 3, 64 * 8, device=DEV)
+    _lib.call("mireg_tiny_deconv3d_bwd_weights", gd.data_ptr(), 16, xd.data_ptr(), 8, slab.data_ptr(), nb, 8, B, Dc, Hc, Wc, code, st)
+    gw = slab.sum(0).view(3, 64, 8)[..., :3].permute(0, 2, 1).reshape(3, 3, 4, 4, 4).cpu()    # [co][tap][ci] -> [co][ci][tap]
+    assert (gw - wr.grad).abs().max().item() <= tol * max(1.0, wr.grad.abs().max().item())
+    assert (slab.view(nb, 3, 64, 8)[..., 3:] == 0).all()
