@@ -550,8 +550,9 @@ bn_elementwise_kernel(const T* __restrict__ y, long ld_y, const T* __restrict__ 
   const int cpr = C / V;
   const long total = M * cpr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / cpr;
-    const int c0 = (int)(i - m * cpr) * V;
+    long rc;
+    const long m = fast_divmod(i, cpr, rc);
+    const int c0 = (int)rc * V;
     float yv[V], g[V], o[V];
     if constexpr (VECT) { ldv(y + m * ld_y + c0, yv); if (MODE == 1) ldv(da + m * ld_da + c0, g); }
     else { yv[0] = ldf(y + m * ld_y + c0); if (MODE == 1) g[0] = ldf(da + m * ld_da + c0); }
@@ -578,8 +579,9 @@ lrelu_bwd_kernel(T* __restrict__ g, long ld_g, const T* __restrict__ a, long ld_
   const int cpr = C / V;
   const long total = M * cpr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / cpr;
-    const int c0 = (int)(i - m * cpr) * V;
+    long rc;
+    const long m = fast_divmod(i, cpr, rc);
+    const int c0 = (int)rc * V;
     float gv[V], av[V];
     if constexpr (VECT) { ldv(g + m * ld_g + c0, gv); ldv(a + m * ld_a + c0, av); }
     else { gv[0] = ldf(g + m * ld_g + c0); av[0] = ldf(a + m * ld_a + c0); }
@@ -595,7 +597,9 @@ __global__ void __launch_bounds__(256)
 cast_from_f32_kernel(T* __restrict__ dst, long ld_d, const float* __restrict__ src, long ld_s, long M, int C, float alpha, float beta) {
   const long total = M * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / C; const int c = (int)(i - m * C);
+    long rc;
+    const long m = fast_divmod(i, C, rc);
+    const int c = (int)rc;
     const float v = alpha * ldf(src + m * ld_s + c) + (beta != 0.f ? beta * ldf(dst + m * ld_d + c) : 0.f);
     stf(dst + m * ld_d + c, v);
   }
@@ -605,7 +609,9 @@ __global__ void __launch_bounds__(256)
 cast_to_f32_kernel(float* __restrict__ dst, long ld_d, const T* __restrict__ src, long ld_s, long M, int C, float alpha, float beta) {
   const long total = M * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / C; const int c = (int)(i - m * C);
+    long rc;
+    const long m = fast_divmod(i, C, rc);
+    const int c = (int)rc;
     stf(dst + m * ld_d + c, alpha * ldf(src + m * ld_s + c) + (beta != 0.f ? beta * ldf(dst + m * ld_d + c) : 0.f));
   }
 }

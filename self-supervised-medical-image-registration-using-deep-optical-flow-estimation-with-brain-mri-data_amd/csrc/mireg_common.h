@@ -47,6 +47,20 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float* red) {
   }
 }
 
+// q = i / d, rem = i % d for a non-negative flat index: ONE 32-bit division when both fit 32 bits (every launch of this library does), the
+// 64-bit pair otherwise.  A 64-bit division is ~100 vector instructions; per-element index splits with two or three of them made the
+// elementwise / resize / tail kernels ALU-bound.
+__device__ __forceinline__ long fast_divmod(long i, long d, long& rem) {
+  if ((((unsigned long)i | (unsigned long)d) >> 32) == 0) {
+    const unsigned q = (unsigned)i / (unsigned)d;
+    rem = (long)((unsigned)i - q * (unsigned)d);
+    return (long)q;
+  }
+  const long q = i / d;
+  rem = i - q * d;
+  return q;
+}
+
 // Charbonnier penalty (x^2 + eps^2)^0.25 with eps = 1e-9 (reference loss.py:33-35).  The argument of every root here lies in
 // [1e-18, 1e18]: normal floats, so the bare v_sqrt_f32 / v_rsq_f32 (1 ulp) replace sqrtf / rsqrtf, whose denormal scaling and
 // refinement steps cost ~25 vector instructions each and made the smoothness kernels ALU-bound (47 -> ~8 instructions per term).

@@ -335,7 +335,10 @@ thin_shift_sum_kernel(const float* __restrict__ z, long ld_z, const float* __res
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int co = (int)(i & 1);
     const long p = i >> 1;
-    const int xx = (int)(p % W), yy = (int)((p / W) % H);
+    long rx, ry;
+    const long qy = fast_divmod(p, W, rx);
+    (void)fast_divmod(qy, H, ry);
+    const int xx = (int)rx, yy = (int)ry;
     float acc = bias ? bias[co] : 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -377,8 +380,9 @@ tiny_deconv_fwd_kernel(const T* __restrict__ xc, long ld_c, const float* __restr
   const int Hf = 2 * Hc, Wf = 2 * Wc_;
   const long n = (long)B * Hf * Wf;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
-    const int ix = (int)(p % Wf), iy = (int)((p / Wf) % Hf);
-    const long b = p / ((long)Wf * Hf);
+    long rx, ry;
+    const long qy = fast_divmod(p, Wf, rx), b = fast_divmod(qy, Hf, ry);
+    const int ix = (int)rx, iy = (int)ry;
     float a0 = bias ? bias[0] : 0.f, a1 = bias ? bias[1] : 0.f;
 #pragma unroll
     for (int ty = 0; ty < 2; ++ty) {
@@ -407,8 +411,9 @@ tiny_conv_fwd_kernel(const T* __restrict__ xf, long ld_f, const float* __restric
   const int Hf = 2 * Hc, Wf = 2 * Wc_;
   const long n = (long)B * Hc * Wc_;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
-    const int ox = (int)(p % Wc_), oy = (int)((p / Wc_) % Hc);
-    const long b = p / ((long)Wc_ * Hc);
+    long rx, ry;
+    const long qy = fast_divmod(p, Wc_, rx), b = fast_divmod(qy, Hc, ry);
+    const int ox = (int)rx, oy = (int)ry;
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
@@ -448,8 +453,9 @@ tiny_wgrad_kernel(const T* __restrict__ xf, long ld_f, const T* __restrict__ dyc
 #pragma unroll
   for (int i = 0; i < 64; ++i) acc[i] = 0.f;
   for (long p = p0 + threadIdx.x; p < p1; p += 256) {
-    const int ox = (int)(p % Wc_), oy = (int)((p / Wc_) % Hc);
-    const long b = p / ((long)Wc_ * Hc);
+    long rx, ry;
+    const long qy = fast_divmod(p, Wc_, rx), b = fast_divmod(qy, Hc, ry);
+    const int ox = (int)rx, oy = (int)ry;
     const float g0 = (float)dyc[p * ld_c], g1 = (float)dyc[p * ld_c + 1];
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {

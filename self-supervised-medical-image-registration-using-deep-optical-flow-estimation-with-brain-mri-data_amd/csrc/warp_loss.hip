@@ -18,6 +18,21 @@ using namespace mireg;
 
 namespace {
 
+// flat index -> (sample, pixel, row, column).  The launches here cover a few million pixels: 32-bit divisions (a dozen instructions) instead
+// of two 64-bit ones (a hundred each) whenever the index fits, which it always does below 2^32 pixels per call.
+__device__ __forceinline__ void split_pixel(long i, long npix, int w, int& b, long& pix, int& y, int& x) {
+  if (((unsigned long)i >> 32) == 0 && ((unsigned long)npix >> 32) == 0) {
+    const unsigned iu = (unsigned)i, nu = (unsigned)npix;
+    const unsigned bu = iu / nu, pu = iu - bu * nu, yu = pu / (unsigned)w;
+    b = (int)bu; pix = (long)pu; y = (int)yu; x = (int)(pu - yu * (unsigned)w);
+  } else {
+    b = (int)(i / npix);
+    pix = i - (long)b * npix;
+    y = (int)(pix / w);
+    x = (int)(pix - (long)y * w);
+  }
+}
+
 constexpr int kThreads = 256;
 constexpr int kSlots = MIREG_SUM_SLOTS;   // moment tables are replicated: block b adds into slot b % kSlots (no hot line)
 
@@ -35,10 +50,9 @@ resize_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int N, 
                   long isn, long isc, long isp, long osn, long osc, long osp, float sy, float sx, int align) {
   const long total = (long)N * C * h * w;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % w);
-    const int y = (int)((i / w) % h);
-    const int c = (int)((i / ((long)w * h)) % C);
-    const int n = (int)(i / ((long)w * h * C));
+    long r0, r1, r2;
+    const long q0 = fast_divmod(i, w, r0), q1 = fast_divmod(q0, h, r1);
+    const int x = (int)r0, y = (int)r1, n = (int)fast_divmod(q1, C, r2), c = (int)r2;
     int y0, y1, x0, x1;
     float ly, lx;
     src_coord(y, sy, align, H, y0, y1, ly);
@@ -70,10 +84,9 @@ resize_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, int N
                   float beta) {
   const long total = (long)N * C * H * W;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int X = (int)(i % W);
-    const int Y = (int)((i / W) % H);
-    const int c = (int)((i / ((long)W * H)) % C);
-    const int n = (int)(i / ((long)W * H * C));
+    long r0, r1, r2;
+    const long q0 = fast_divmod(i, W, r0), q1 = fast_divmod(q0, H, r1);
+    const int X = (int)r0, Y = (int)r1, n = (int)fast_divmod(q1, C, r2), c = (int)r2;
     int ylo, yhi, xlo, xhi;
     out_range(Y, sy, align, h, ylo, yhi);
     out_range(X, sx, align, w, xlo, xhi);
@@ -127,9 +140,9 @@ stn_warp_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (long gidx = (long)blockIdx.x * blockDim.x + threadIdx.x; gidx < groups; gidx += (long)gridDim.x * blockDim.x) {
     const long p0 = gidx * VEC;
-    const int b = (int)(p0 / npix);
-    const long pix = p0 - (long)b * npix;
-    const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    int b, y, x;
+    long pix;
+    split_pixel(p0, npix, w, b, pix, y, x);
     float u[VEC], v[VEC];
     const float* fu = flow + b * fsb + pix * fsp;
     if (VEC == 4 && fsp == 1) {
@@ -200,9 +213,9 @@ stn_warp_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp
   const float two_w = (float)(2.0 / (double)w), two_h = (float)(2.0 / (double)h);
   const float kx = (float)(w - 1) / (float)w * 1.f, ky = (float)(h - 1) / (float)h * 1.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / npix);
-    const long pix = i - (long)b * npix;
-    const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    int b, y, x;
+    long pix;
+    split_pixel(i, npix, w, b, pix, y, x);
     const float* fu = flow + b * fsb + pix * fsp;
     const float px = stn_coord((float)x, fu[0], two_w, (float)(w - 1));
     const float py = stn_coord((float)y, fu[fsc], two_h, (float)(h - 1));
@@ -272,9 +285,9 @@ smooth_fwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, 
   const long npix = (long)h * w, total = (long)B * npix;
   float acc[1] = {0.f};
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / npix);
-    const long pix = i - (long)b * npix;
-    const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    int b, y, x;
+    long pix;
+    split_pixel(i, npix, w, b, pix, y, x);
     const float* f = flow + b * fsb + pix * fsp;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -294,9 +307,9 @@ smooth_bwd_kernel(const float* __restrict__ flow, long fsb, long fsc, long fsp, 
   const float cs = coef[5];
   const long npix = (long)h * w, total = (long)B * npix;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / npix);
-    const long pix = i - (long)b * npix;
-    const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    int b, y, x;
+    long pix;
+    split_pixel(i, npix, w, b, pix, y, x);
     const float* f = flow + b * fsb + pix * fsp;
     float* g = gflow + b * gsb + pix * gsp;
 #pragma unroll
@@ -432,9 +445,10 @@ affine_sample3d_kernel(const float* __restrict__ vol, const float* __restrict__ 
                        int B, int C, int D, int H, int W) {
   const long nvox = (long)D * H * W, total = (long)B * nvox;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / nvox);
-    const long v = i - (long)b * nvox;
-    const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((long)W * H));
+    long v, r0, r1;
+    const int b = (int)fast_divmod(i, nvox, v);
+    const long q0 = fast_divmod(v, W, r0);
+    const int x = (int)r0, z = (int)fast_divmod(q0, H, r1), y = (int)r1;
     const float* t = theta + b * 12;
     // affine_grid base coordinates (align_corners=False): (2i + 1)/n - 1
     const float bx = (2.f * x + 1.f) / (float)W - 1.f, by = (2.f * y + 1.f) / (float)H - 1.f, bz = (2.f * z + 1.f) / (float)D - 1.f;
@@ -545,9 +559,9 @@ tail_resize_kernel(const mireg_tail_job* __restrict__ jobs, int n, const float* 
   for (int chunk = 0; chunk < MIREG_TAIL_PIXELS_PER_BLOCK / kThreads; ++chunk) {
   const long i = ((long)(blockIdx.x - j.blk0) * (MIREG_TAIL_PIXELS_PER_BLOCK / kThreads) + chunk) * kThreads + threadIdx.x;
   if (i >= (long)B * npix) return;
-  const int b = (int)(i / npix);
-  const long pix = i - (long)b * npix;
-  const int y = (int)(pix / j.w), xx = (int)(pix - (long)y * j.w);
+  int b, y, xx;
+  long pix;
+  split_pixel(i, npix, j.w, b, pix, y, xx);
   const float* fixed = x + (long)b * 2 * H * W;
   const float* moving = fixed + (long)H * W;
 #pragma unroll
@@ -576,9 +590,9 @@ tail_fwd_kernel(const mireg_tail_job* __restrict__ jobs, int n, int B) {
   for (int chunk = 0; chunk < MIREG_TAIL_PIXELS_PER_BLOCK / kThreads; ++chunk) {     // fewer blocks = fewer f64 atomics per moment
     const long i = ((long)(blockIdx.x - j.blk0) * (MIREG_TAIL_PIXELS_PER_BLOCK / kThreads) + chunk) * kThreads + threadIdx.x;
     if (i >= (long)B * npix) continue;
-    const int b = (int)(i / npix);
-    const long pix = i - (long)b * npix;
-    const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    int b, y, x;
+    long pix;
+    split_pixel(i, npix, w, b, pix, y, x);
     const float* f = j.flow + b * j.fsb + pix * j.fsp;
     const float u = f[0], v = f[j.fsc];
     const float px = stn_coord((float)x, u, (float)(2.0 / (double)w), (float)(w - 1));
@@ -618,9 +632,9 @@ tail_bwd_kernel(const mireg_tail_job* __restrict__ jobs, int n, int B) {
   for (int chunk = 0; chunk < MIREG_TAIL_PIXELS_PER_BLOCK / kThreads; ++chunk) {
   const long i = ((long)(blockIdx.x - j.blk0) * (MIREG_TAIL_PIXELS_PER_BLOCK / kThreads) + chunk) * kThreads + threadIdx.x;
   if (i >= (long)B * npix) return;
-  const int b = (int)(i / npix);
-  const long pix = i - (long)b * npix;
-  const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+  int b, y, x;
+  long pix;
+  split_pixel(i, npix, w, b, pix, y, x);
   const float* f = j.flow + b * j.fsb + pix * j.fsp;
   // d loss / d warped (loss.py:38-50 photometric + NCC through the scale's moments)
   const float xv = j.warped[i], yv = j.fixed_r[i];
