@@ -438,7 +438,7 @@ class ConvLayer:
         d.split_k, d.algo, d.tile_m = 1, 0, 0
         htiles = (ctypes.c_long * 2)()
         halo = USE_HALO and bool(_lib.lib().mireg_conv_halo_eligible(ctypes.byref(d), htiles))
-        if halo:
+        if halo and N >= 64:                               # below 64 columns only as a measured candidate (half-empty 64-column tiles)
             tn = (N + bn - 1) // bn
             tm = 256 if (htiles[1] and htiles[1] * tn * ncls >= 224) else (128 if htiles[0] else 256)
             heur = (bn, 1, 2, tm)
@@ -457,7 +457,7 @@ class ConvLayer:
             if halo:
                 for i, tm in enumerate((128, 256)):
                     if htiles[i]:
-                        cands.add((b, 1, 2, tm))
+                        cands.add((max(b, 64) if N <= 64 else b, 1, 2, tm))
         # the 256-pixel 8-wave tile (conv_wide.hip): 256 or 128 columns, split-K where the grid would leave CUs idle
         if USE_WIDE and self.ws.code == DT_BF16 and bool(_lib.lib().mireg_conv_wide_eligible(ctypes.byref(d), None)):
             nk64 = (K + 63) // 64
@@ -541,7 +541,7 @@ class ConvLayer:
     def _family(N: int, split: int, tile_n: int = 0, algo: int = 1, tile_m: int = 0) -> str:
         bn = tile_n or (128 if N > 64 else (64 if N > 32 else 32))
         if algo == 2:
-            return f"conv_halo_kernel<{tile_m},{bn}>"
+            return f"conv_halo_kernel<{tile_m},{max(bn, 64)}>"
         if algo == 3:
             return f"conv_wide_kernel<256,{bn}>" + ("+splitk" if split > 1 else "")
         return f"conv_gemm_kernel<128,{bn}>" + ("+splitk" if split > 1 else "")
