@@ -15,8 +15,10 @@ import torch.nn as nn
 
 from . import _lib
 from . import engine as engine_mod
-from .engine import (DT_BF16, F32, BatchNormAct, ConvLayer, View, WoptJob, Workspace, _stream, assign_tiles, cast_from_f32, zero_tensors,
+from .engine import (DT_BF16, F32, TINY_MASK, BatchNormAct, ConvLayer, View, WoptJob, Workspace, _stream, assign_tiles, cast_from_f32, zero_tensors,
                      lrelu_bwd, nchw_to_view, upload_table)
+
+FORK_DECODER = os.environ.get("MIREG_SERIAL_DECODER", "0") != "1"   # A/B switch: decoder heads next to the deconvolutions
 
 ENCODER = [  # name, cin, cout, k, stride   (FlowNetS/FlowNetS.py:17-26)
     ("conv1", 2, 64, 7, 2), ("conv2", 64, 128, 5, 2), ("conv3", 128, 256, 5, 2), ("conv3_1", 256, 256, 3, 1),
@@ -406,16 +408,38 @@ class FlowNetDecoderMixin:
         self.flowT = {lvl: new(B, *hs[lvl], 2) for lvl in PREDICT}
 
     def decoder_forward(self) -> None:
+        """Per level: deconv(feat) and [predict_flow(feat) -> flow upsampler] only share their input, and the forward pass has the chip
+        to itself at concurrency 1 (profiles/round3_step_timeline.txt): the head branch (15-25 us of vector-ALU kernels) runs on the
+        second stream next to the deconvolution GEMM and is joined before the level's concat is read.  Only when both head layers
+        take their scratch-free kernels (a split-K GEMM on either branch would share the workspace slab) and not while launch shapes
+        are being timed."""
         L, c = self.layers, self.cat
         feat = self.a61
-        L["predict_flow6"].run_fwd_form(feat, self.flowT[6], y32=self.flow32[6])
+        par = (FORK_DECODER and self.use_side_stream and not self.ws.tuning
+               and all(L[f"predict_flow{l}"].thin for l in (6, 5, 4, 3)) and all(L[f"up{l}"].tiny for l in (6, 5, 4, 3)) and (TINY_MASK & 1))
+        main = torch.cuda.current_stream()
+        if par and getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.ws.device)
         for lvl in (5, 4, 3, 2):
             cs = self.skip_c[lvl]
             cd = DECONV[lvl][1]
-            L[f"up{lvl + 1}"].run_dgrad_form(self.flowT[lvl + 1], c[lvl].slice(cs + cd, 2), bias=True)
+
+            def heads(feat=feat, lvl=lvl, cs=cs, cd=cd):
+                L[f"predict_flow{lvl + 1}"].run_fwd_form(feat, self.flowT[lvl + 1], y32=self.flow32[lvl + 1])
+                L[f"up{lvl + 1}"].run_dgrad_form(self.flowT[lvl + 1], c[lvl].slice(cs + cd, 2), bias=True)
+            if par:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._side.wait_event(ev)
+                with torch.cuda.stream(self._side):
+                    heads()
+            else:
+                heads()
             L[f"deconv{lvl}"].run_dgrad_form(feat, c[lvl].slice(cs, cd), slope=SLOPE, bias=True)
+            if par:
+                main.wait_stream(self._side)
             feat = c[lvl]
-            L[f"predict_flow{lvl}"].run_fwd_form(feat, self.flowT[lvl], y32=self.flow32[lvl])
+        L["predict_flow2"].run_fwd_form(feat, self.flowT[2], y32=self.flow32[2])
 
     def setup_decoder_grads(self) -> None:
         new, hs, B = self.ws.new, self.hs, self.B
