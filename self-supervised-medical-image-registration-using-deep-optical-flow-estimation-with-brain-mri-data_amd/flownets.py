@@ -439,7 +439,16 @@ class FlowNetDecoderMixin:
             if par:
                 main.wait_stream(self._side)
             feat = c[lvl]
+        hook = getattr(self, "pre_tail", None)                                # the trainer's batch-only loss preparation (FusedRegLoss.prepare)
+        if par and hook is not None:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                hook()
         L["predict_flow2"].run_fwd_form(feat, self.flowT[2], y32=self.flow32[2])
+        if par and hook is not None:
+            main.wait_stream(self._side)
 
     def setup_decoder_grads(self) -> None:
         new, hs, B = self.ws.new, self.hs, self.B

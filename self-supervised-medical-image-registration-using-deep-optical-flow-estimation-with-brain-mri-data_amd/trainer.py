@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -35,6 +37,9 @@ def flatten_parameters(module: nn.Module) -> torch.Tensor:
         p.data = flat[o:o + n].view(p.shape)
         o += n
     return flat
+
+
+TAIL_PREPARE_EARLY = os.environ.get("MIREG_TAIL_SERIAL", "0") != "1"     # A/B switch
 
 
 class FusedRegLoss:
@@ -77,19 +82,37 @@ class FusedRegLoss:
             self._tab, self._tab_blocks, self._tab_key = upload_table(jobs, self.dev), blk, key
         return self._tab, self._tab_blocks
 
+    def prepare(self, x: torch.Tensor) -> bool:
+        """The part of forward() that depends on the batch only -- clearing the moment table and resizing fixed / moving to every flow
+        scale -- on the current stream, so that it can run next to the last kernels of the predictor's forward pass.  Needs the job
+        table of an earlier forward() (the flow buffers are the engine's, fixed after the first step); False when there is none yet."""
+        if not self.fused or getattr(self, "_tab_key", None) is None:
+            return False
+        B, H, W = self.B, self.H, self.W
+        zero_tensors([self.sums])
+        npx = sum(B * h * w for h, w in self.sizes)
+        PROFILER.call("tail_resize", 8.0 * B * H * W + 8.0 * npx, "tail:resize", "mireg_tail_resize", self._tab.data_ptr(), self.n,
+                      self._tab_blocks, x.data_ptr(), B, H, W, _stream(), unit="B")
+        self._prepared = True
+        return True
+
     def forward(self, x: torch.Tensor, flows: Sequence[torch.Tensor]) -> torch.Tensor:
         """x: (B,2,H,W) contiguous fp32 [fixed, moving]; flows[i]: logical (B,2,h,w) fp32 (any pixel stride)."""
         B, H, W, st = self.B, self.H, self.W, _stream()
         HW = H * W
         fixed_ptr, moving_ptr = x.data_ptr(), x.data_ptr() + HW * 4
-        zero_tensors([self.sums])                           # HIP fill (no ATen launch inside the step)
+        prepared, self._prepared = getattr(self, "_prepared", False), False
         if self.fused:
+            key = getattr(self, "_tab_key", None)
             tab, blocks = self._table(flows)
             npx = sum(B * h * w for h, w in self.sizes)          # algorithmic HBM bytes: DESIGN.md section 6
-            PROFILER.call("tail_resize", 8.0 * B * H * W + 8.0 * npx, "tail:resize", "mireg_tail_resize", tab.data_ptr(), self.n,
-                          blocks, x.data_ptr(), B, H, W, st, unit="B")
+            if not prepared or key != self._tab_key:             # (a prepare() against a stale table is simply redone)
+                zero_tensors([self.sums])                        # HIP fill (no ATen launch inside the step)
+                PROFILER.call("tail_resize", 8.0 * B * H * W + 8.0 * npx, "tail:resize", "mireg_tail_resize", tab.data_ptr(), self.n,
+                              blocks, x.data_ptr(), B, H, W, st, unit="B")
             PROFILER.call("tail_fwd", 20.0 * npx, "tail:fwd", "mireg_tail_fwd", tab.data_ptr(), self.n, blocks, B, st, unit="B")
             return self.sums
+        zero_tensors([self.sums])
         for i, (h, w) in enumerate(self.sizes):
             _lib.call("mireg_resize_bilinear_fwd", moving_ptr, self.moving_r[i].data_ptr(), B, 1, H, W, h, w,
                       2 * HW, HW, 1, h * w, h * w, 1, 1, st)
@@ -260,8 +283,10 @@ class RegistrationTrainer:
 
     def _forward_and_loss(self):
         self.eng.packs_fresh = self._packs_fresh          # the fused optimizer rewrote the packs with the weights
+        # the loss tail's batch-only part rides the decoder's second stream next to the last head of the forward pass (decoder_forward)
+        self.eng.pre_tail = (lambda: self.loss.prepare(self.x_static)) if (TAIL_PREPARE_EARLY and not self._tuning) else None
         flows = self.eng.forward(self.x_static, True)
-        self.eng.packs_fresh = False
+        self.eng.packs_fresh, self.eng.pre_tail = False, None
         self.loss.forward(self.x_static, flows)
         Bg = self.loss.B * self.world if self.sync_loss_stats else None
         if self.sync_loss_stats:
