@@ -556,6 +556,12 @@ def main():
                 loss.backward()
                 opt2.step()
                 return loss.detach()
+            f2_train()
+
+            def f2_fwd_bwd():                                        # launch shapes measured once on the real buffers (mireg.autotune)
+                flows, warped, _, _ = reg2(x2)
+                mireg.OFEloss(flows, warped, x2[:, 0:1])[3].backward()
+            n_sites = mireg.autotune(reg2, f2_fwd_bwd)
             for _ in range(2):
                 f2_train()
             torch.cuda.synchronize()
@@ -565,7 +571,7 @@ def main():
             torch.cuda.synchronize()
             dt2 = (time.perf_counter() - t0) / 4
             others["flownet2_train"] = {"pairs_per_s": round(8 / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3), "batch": 8, "loss_total": float(l2.detach()),
-                                        "note": "forward + OFEloss + HIP backward of the five sub-networks through torch.autograd + mireg.Adam(fuse=model), eager; hipgraph = the same step replayed from one hipGraph"}
+                                        "note": "forward + OFEloss + HIP backward of the five sub-networks through torch.autograd + mireg.Adam(fuse=model), launch shapes from mireg.autotune, eager; hipgraph = the same step replayed from one hipGraph", "tuned_sites": n_sites}
             log(f"flownet2 train batch 8: {8 / dt2:.1f} pairs/s")
             try:                                                     # the same step replayed from one hipGraph (the eager form is host-bound)
                 import gc

@@ -29,6 +29,13 @@ def timed(fn, n=5, warm=2):
         out = fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3, out
+if os.environ.get("TUNE"):
+    def fb():
+        flows, warped, _, _ = reg2(x2)
+        mireg.OFEloss(flows, warped, x2[:, 0:1])[3].backward()
+    step()
+    t0 = time.perf_counter()
+    print("tuned sites:", mireg.autotune(reg2, fb), f"in {time.perf_counter() - t0:.1f} s", flush=True)
 t, l = timed(step)
 print(f"eager {t:.2f} ms/step  loss {float(l):.3f}", flush=True)
 if len(sys.argv) < 2:

@@ -18,10 +18,11 @@ from .flownets3d import FlowNetS3D, opticalFlowReg3d  # noqa: F401
 from .models import generate_grid, grid_generator, opticalFlowReg  # noqa: F401
 from .trainer import RegistrationTrainer  # noqa: F401
 from .optim import Adam  # noqa: F401
+from .tuning import autotune  # noqa: F401
 from . import checkpoint  # noqa: F401
 from .flownet2_ops import ChannelNorm, Resample2d, Upsample  # noqa: F401
 from .flownet2 import FlowNet2, FlowNet2S, FlowNetFusion, FlowNetSD  # noqa: F401
 from .metrics import (CORR, MI, MSE, PSNR, dist_hausdorff, extract_boundary_points, modified_hausdorff, pair_metrics, ssim_batch,  # noqa: F401
                       structural_similarity)
 
-__all__ = ["dist_hausdorff", "extract_boundary_points", "FlowNet2", "FlowNet2S", "FlowNetSD", "FlowNetFusion", "modified_hausdorff", "structural_similarity", "ssim_batch", "Resample2d", "ChannelNorm", "Upsample", "MSE", "PSNR", "CORR", "MI", "pair_metrics", "Adam", "FlowNetS3D", "opticalFlowReg3d", "OFEloss3d", "stn3d", "resize_trilinear", "smoothness_loss_3d", "affmodel", "Affloss", "FlowNetS", "FlowNetC", "PWCDCNet", "Correlation", "opticalFlowReg", "RegistrationTrainer", "generate_grid", "grid_generator", "OFEloss", "photometric_loss", "correlation_loss", "smoothness_loss", "photometric_loss_3d", "correlation_loss_3d", "dice_average", "dice_batch", "resize_bilinear", "seg_round", "stn"]
+__all__ = ["autotune", "dist_hausdorff", "extract_boundary_points", "FlowNet2", "FlowNet2S", "FlowNetSD", "FlowNetFusion", "modified_hausdorff", "structural_similarity", "ssim_batch", "Resample2d", "ChannelNorm", "Upsample", "MSE", "PSNR", "CORR", "MI", "pair_metrics", "Adam", "FlowNetS3D", "opticalFlowReg3d", "OFEloss3d", "stn3d", "resize_trilinear", "smoothness_loss_3d", "affmodel", "Affloss", "FlowNetS", "FlowNetC", "PWCDCNet", "Correlation", "opticalFlowReg", "RegistrationTrainer", "generate_grid", "grid_generator", "OFEloss", "photometric_loss", "correlation_loss", "smoothness_loss", "photometric_loss_3d", "correlation_loss_3d", "dice_average", "dice_batch", "resize_bilinear", "seg_round", "stn"]

@@ -220,13 +220,24 @@ class Workspace:
         # discarded tuning pass, `tuned` maps a launch site to its measured-best (tile_n, split_k)
         self.wgrad_stages = 3                              # mireg_conv_desc.stages of the backward-weights GEMM (3 or 4)
         self.colsum_ws: Optional[torch.Tensor] = None      # row-segment partials of the bias-gradient column sums
-        self.tuning = False
+        self._tuning = False
         self.tuned: Dict[tuple, Tuple[int, int]] = {}
         self.tuned_wgrad: Dict[str, list] = {}             # layer name -> measured [split-K, algo] of its backward-weights GEMM
 
     def new(self, B: int, H: int, W: int, C: int, dtype: Optional[torch.dtype] = None, pad: int = 8) -> View:
         buf = torch.zeros(B, H, W, rup(C, pad), device=self.device, dtype=dtype or self.dtype)
         return View(buf, B, H, W, C, 0)
+
+    # `tuning`: on during a discarded tuning pass -- the trainer's own (per workspace) or mireg.autotune's (TUNE_ALL, every workspace)
+    TUNE_ALL = False
+
+    @property
+    def tuning(self) -> bool:
+        return self._tuning or Workspace.TUNE_ALL
+
+    @tuning.setter
+    def tuning(self, on: bool) -> None:
+        self._tuning = bool(on)
 
     def save_tuning(self, path: str) -> None:
         import json

@@ -230,3 +230,48 @@ def test_packed_domain_adam_under_autograd_matches_the_plain_optimizer(name):
     flows, warped, _, _ = mb(x)
     with pytest.raises(RuntimeError, match="second backward"):
         mireg.OFEloss(flows, warped, x[:, 0:1])[3].backward()
+
+
+def test_autotune_leaves_the_training_state_untouched_and_training_equivalent():
+    """mireg.autotune(model, run): one discarded forward + backward in which every engine times its launch shapes.  Afterwards the
+    parameters, their `.grad`, the BatchNorm running statistics / batch counters and a packed-domain optimizer's pending state are what
+    they were, sites are recorded, and three training steps give the losses of an untuned twin (fp32: different split-K orders only)."""
+    import mireg
+    from mireg.synth import make_pairs
+    x, _ = make_pairs(2, 128, seed=9)
+    x = x.to(DEV)
+
+    def build():
+        torch.manual_seed(21)
+        m = mireg.opticalFlowReg("flownetc", precision="fp32").to(DEV).train()
+        return m, mireg.Adam(m.parameters(), 1e-4, eps=1e-4, fuse=m)
+
+    def fwd_bwd(m):
+        flows, warped, _, _ = m(x)
+        loss = mireg.OFEloss(flows, warped, x[:, 0:1])[3]
+        loss.backward()
+        return loss.detach()
+
+    def step(m, opt):
+        opt.zero_grad()
+        loss = fwd_bwd(m)
+        opt.step()
+        return float(loss)
+
+    (ma, oa), (mb, ob) = build(), build()
+    step(ma, oa), step(mb, ob)
+    before = {k: v.detach().clone() for k, v in mb.state_dict().items()}
+    gbefore = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in mb.named_parameters()}
+    n = mireg.autotune(mb, lambda: fwd_bwd(mb))
+    assert n > 20
+    for k, v in mb.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    for k, p in mb.named_parameters():
+        assert (p.grad is None) == (gbefore[k] is None) and (p.grad is None or torch.equal(p.grad, gbefore[k])), k
+    for _ in range(3):
+        la, lb = step(ma, oa), step(mb, ob)
+        assert abs(la - lb) <= 2e-4 * abs(la), (la, lb)
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        if "num_batches_tracked" in k:
+            assert int(sa[k]) == int(sb[k]), k
