@@ -13,6 +13,7 @@ conv6's output for other volume sizes.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, Tuple
 
@@ -70,6 +71,7 @@ def _vol(x, dims) -> Vol:
     return x if isinstance(x, Vol) else Vol(x, tuple(dims), x.shape[-1], 0)
 
 
+WGRAD_PER_TAP = os.environ.get("MIREG_3D_WGRAD_PER_TAP", "0") == "1"    # A/B switch: one backward-weights launch per depth tap
 FORCE_WIDE = None      # tests only: None = heuristic, (128,) / (256,) = always the 256-pixel tile at that width, () = never
 
 
@@ -239,15 +241,18 @@ class Conv3dLayer:
         B = x.B
         P = B * odims[0] * odims[1] * odims[2]
         K2 = self.kh * self.kw * self.Cip
-        tiles = ((self.Co + 127) // 128) * ((K2 + 127) // 128)            # per launch (the depth taps run back to back)
+        tiles = ((self.Co + 127) // 128) * ((K2 + 127) // 128) * (1 if WGRAD_PER_TAP else self.kd)   # workgroups per pixel split
         nk = (P + 31) // 32
         split = 1 if tiles >= 256 else max(1, min(768 // tiles, max(nk // 8, 1)))      # up to three workgroups per CU resident
         if getattr(self, "slab", None) is None or self.slab.shape[0] != split:
             self.slab = torch.zeros(split, self.Co, self.Kf, device=x.buf.device, dtype=torch.float32)
-        for tz in range(self.kd):
+        # one launch for all depth taps (grid.y = tap): the tap-variants of a pixel chunk run back to back and find its dy / x tiles in
+        # the cache hierarchy; one launch per tap (WGRAD_PER_TAP, the round-2 form) swept both operands from HBM kd times
+        for tz in (range(self.kd) if WGRAD_PER_TAP else (0,)):
             d = ConvDesc()
             d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = x.ptr, x.ld, idims[0], idims[1], idims[2], self.Cip
             d.taps_y, d.taps_x = self.kh, self.kw
+            d.taps_z = 0 if WGRAD_PER_TAP else self.kd
             d.mul_z, d.mul_y, d.mul_x = self.stride
             d.off_z, d.off_y, d.off_x = tz - self.pad[0], -self.pad[1], -self.pad[2]
             d.step_y = d.step_x = 1
@@ -256,7 +261,9 @@ class Conv3dLayer:
             d.split_k, d.dtype, d.stages = split, self.ws.code, 3
             d.slab, d.slab_ld = self.slab.data_ptr() + 4 * tz * K2, self.Kf
             d.x_bytes, d.w_bytes = x.bytes_left, gy.bytes_left
-            PROFILER.launch("mireg_conv_wgrad", d, "conv3d_wgrad", 2.0 * P * self.Co * K2, f"conv3d-wgrad tz={tz}")
+            d.algo = 1                                                            # the LDS-DMA ring kernel (the only one with a depth axis)
+            PROFILER.launch("mireg_conv_wgrad", d, "conv3d_wgrad", 2.0 * P * self.Co * K2 * (1 if WGRAD_PER_TAP else self.kd),
+                            f"conv3d-wgrad {'tz=%d' % tz if WGRAD_PER_TAP else 'all taps'}")
 
     @staticmethod
     def unpack_grads(pairs, ws: Workspace):

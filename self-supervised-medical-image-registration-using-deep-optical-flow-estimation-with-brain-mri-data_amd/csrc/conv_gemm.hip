@@ -742,7 +742,7 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
     s_ix[c] = p_gx[c] * p.mul_x + b_dx;
     const int vol = img / gD;
     p_gz[c] = img - vol * gD;
-    s_iz[c] = p_gz[c] * mulz + p.off_z;
+    s_iz[c] = p_gz[c] * mulz + p.off_z + (int)blockIdx.y;      // Conv3d: blockIdx.y = depth tap (one launch for all of them)
     a_off[c] = (unsigned)pix[c] * y_ldb + (unsigned)a_col * sz;
     b_off[c] = (unsigned)((vol * xD + s_iz[c]) * (int)IMGB) + (unsigned)(s_iy[c] * (int)ROWB_X) + (unsigned)(s_ix[c] * (int)PIXB) + (unsigned)b_ch * sz;
   }
@@ -870,8 +870,8 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   float* ct = reinterpret_cast<float*>(smem);
   const int Cout = p.N;
   const long sld = p.slab_ld > 0 ? p.slab_ld : Ktot;               // Conv3d: the depth taps share one [Cout][taps_z*Ktot] slab
-  float* __restrict__ slab = p.slab + (long)blockIdx.z * Cout * sld;
-  const bool vec = (Ktot % 4) == 0;
+  float* __restrict__ slab = p.slab + (long)blockIdx.z * Cout * sld + (long)blockIdx.y * Ktot;   // depth tap t fills columns [t*Ktot, (t+1)*Ktot)
+  const bool vec = (Ktot % 4) == 0 && (sld % 4) == 0;
   for (int hp = 0; hp < 2; ++hp) {                                  // rows [64 hp, 64 hp + 64) of the tile
     if (hp) __syncthreads();
     if (wm == hp) {
@@ -944,7 +944,9 @@ int launch_wgrad(const mireg_conv_desc& p, hipStream_t stream) {
   const int Cout = p.N;
   const int Ktot = p.taps_y * p.taps_x * p.x_C;
   const int z = p.split_k > 1 ? p.split_k : 1;
-  dim3 grid((unsigned)(((Cout + 127) / 128) * ((Ktot + 127) / 128)), 1, z);
+  // Conv3d: all depth taps in one launch (grid.y): the tap-variants of a pixel chunk run back to back and share its dy / x tiles in the
+  // cache hierarchy instead of sweeping both operands from HBM once per tap (conv1 of FlowNetS-3D: 7 launches x 112 us -> one)
+  dim3 grid((unsigned)(((Cout + 127) / 128) * ((Ktot + 127) / 128)), (unsigned)(p.taps_z > 1 ? p.taps_z : 1), z);
   if (p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < (1L << 31) && p.w_bytes < (1L << 31))
     // 3 stages = 48 KiB LDS, three workgroups per CU; 4 stages = 64 KiB, two per CU (leaves more of the CU to a concurrent stream)
     if (p.stages == 4) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 4>), grid, dim3(256), 0, stream, p);
@@ -961,7 +963,8 @@ bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
   if (p->dtype != MIREG_DTYPE_BF16 && p->dtype != MIREG_DTYPE_F32) return false;
   if (p->x_C <= 0 || p->x_C % cpc || p->x_ld % cpc || ((uintptr_t)p->x % 16)) return false;
   if ((long)p->n_img * p->g_H * p->g_W * (p->g_D > 0 ? p->g_D : 1) >= (1L << 31)) return false;
-  if (wgrad && p->taps_z > 1) return false;                                 // Conv3d backward-weights: one launch per depth tap
+  if (wgrad && p->taps_z > 1 && !(p->x_bytes > 0 && p->w_bytes > 0 && p->x_bytes < (1L << 31) && p->w_bytes < (1L << 31) && p->algo != 3 &&
+                                   p->slab_ld >= (long)p->taps_z * p->taps_y * p->taps_x * p->x_C)) return false;   // depth taps = grid.y of the LDS-DMA kernel only
   if (wgrad && (p->g_D > 1 || p->x_D > 1) && !(p->x_bytes > 0 && p->w_bytes > 0 && p->x_bytes < (1L << 31) && p->w_bytes < (1L << 31))) return false;
   if (wgrad) {
     if (!p->y || !p->slab || p->y_ld % cpc || ((uintptr_t)p->y % 16)) return false;
