@@ -245,8 +245,9 @@ int mireg_scale_intensity(float* x, int items, long n, float minv, float maxv, f
  * mireg_conv_wgrad reuses the struct: y/y_ld = dy rows over the same logical grid with N = Cout
  * channels, x = the forward input, w_bytes = readable bytes of dy; result slab[split_k][N][taps*x_C] (fp32).
  * x_C, x_ld, w_ld, y_ld (wgrad) must be multiples of 8 (bf16) / 4 (fp32); pad channels must hold zeros. */
-typedef struct mireg_conv_cls {     /* one output-pixel parity class of a stride-2 DGRAD-form launch */
+typedef struct mireg_conv_cls {     /* one output-pixel (-voxel) parity class of a stride-2 DGRAD-form launch */
   int taps_y, taps_x, off_y, off_x, g_H, g_W, y_off_y, y_off_x;
+  int taps_z, off_z, g_D, y_off_z;  /* depth axis of the class (Conv3d, up to 8 classes; ring kernel only); g_D == 0: the launch's own depth fields apply */
   const void* w; long w_ld, w_bytes;
 } mireg_conv_cls;
 typedef struct mireg_conv_desc {
@@ -261,9 +262,9 @@ typedef struct mireg_conv_desc {
   int split_k; float* slab;
   long x_bytes, w_bytes;   /* readable bytes from x / w to the end of their allocations (buffer descriptors of the
                               LDS-DMA tile loads, each < 2 GiB) */
-  int n_cls;               /* 0/1: the fields above describe the launch; 2..4: blockIdx.y picks cls[] (taps, offsets,
+  int n_cls;               /* 0/1: the fields above describe the launch; 2..8: blockIdx.y picks cls[] (more than 4, or classes with a depth axis: ring kernel, algo 1) (taps, offsets,
                               sub-grid, output offset and weights per parity class), everything else is shared */
-  mireg_conv_cls cls[4];
+  mireg_conv_cls cls[8];
   long slab_cls_stride;    /* floats between the split-K slabs of consecutive classes */
   /* optional depth axis for Conv3d (reference models.py:39-43,160-165), NDHWC volumes; all zero for 2-D launches:
    * iz = gz*mul_z + off_z + tz*step_z in [0, x_D); rows run over (n_img, g_D, g_H, g_W); k = ((tz*taps_y+ty)*taps_x+tx)*x_C + c;

@@ -71,6 +71,8 @@ def _vol(x, dims) -> Vol:
     return x if isinstance(x, Vol) else Vol(x, tuple(dims), x.shape[-1], 0)
 
 
+MERGE_ALWAYS = os.environ.get("MIREG_3D_DGRAD_MERGE_ALWAYS", "0") == "1"        # experiment: also where the per-class launches take the 8-wave tile
+MERGE_CLASSES = os.environ.get("MIREG_3D_DGRAD_PER_CLASS", "0") != "1"     # A/B switch: one backward-data launch per parity class
 WGRAD_PER_TAP = os.environ.get("MIREG_3D_WGRAD_PER_TAP", "0") == "1"    # A/B switch: one backward-weights launch per depth tap
 FORCE_WIDE = None      # tests only: None = heuristic, (128,) / (256,) = always the 256-pixel tile at that width, () = never
 
@@ -215,10 +217,14 @@ class Conv3dLayer:
         if not getattr(self, "dfresh", False):
             self._tab3 = self.pack_dgrad_table([self], self.ws)
         self.dfresh = False                                   # the packs serve one backward-data pass; weights may move after it
+        live = []
         for k in self.dgrad_classes():
             g = [(idims[a] - k["par"][a] + self.stride[a] - 1) // self.stride[a] for a in range(3)]
-            if min(g) <= 0:
-                continue
+            if min(g) > 0:
+                live.append((k, g))
+        if len(live) > 1 and MERGE_CLASSES and self._merged_dgrad(live, gy, odims, gx, idims, slope, accumulate):
+            return
+        for k, g in live:
             d = ConvDesc()
             d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = gy.ptr, gy.ld, odims[0], odims[1], odims[2], Cop
             d.taps_z, d.taps_y, d.taps_x = k["nt"]
@@ -233,6 +239,56 @@ class Conv3dLayer:
             d.y_off_z, d.y_off_y, d.y_off_x = k["par"]
             d.slope, d.dtype, d.accumulate = slope, self.ws.code, int(accumulate)
             self._launch(d, B * g[0] * g[1] * g[2], self.Ci, k["pack"].shape[1])
+
+    def _merged_dgrad(self, live, gy: Vol, odims, gx: Vol, idims, slope: float, accumulate: bool) -> bool:
+        """All parity classes of a stride-2 backward-data pass in ONE ring-kernel launch (blockIdx.y = class, mireg_conv_cls with its
+        depth fields) plus one split-K reduce, instead of up to eight of each: the coarse levels' launches are launch-latency sized.
+        Not where the per-class launches take the 8-wave tile (large levels; that kernel runs one class per launch): returns False."""
+        B, Cop, N = gy.B, rup(self.Co, 8), self.Ci
+        Ms = [B * g[0] * g[1] * g[2] for _, g in live]
+        Ks = [k["pack"].shape[1] for k, _ in live]
+        M, Kmin = max(Ms), min(Ks)
+        if self.ws.code == DT_BF16 and engine_mod.USE_WIDE and FORCE_WIDE != () and Cop >= 64 and N >= 16 and min(Ks) >= 64:
+            t256, t128 = ((M + 255) // 256) * ((N + 255) // 256), ((M + 255) // 256) * ((N + 127) // 128)
+            if (FORCE_WIDE or (N > 128 and t256 >= 224) or t128 >= 224) and not MERGE_ALWAYS:
+                return False
+        k0, g0 = live[0]
+        d = ConvDesc()
+        d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = gy.ptr, gy.ld, odims[0], odims[1], odims[2], Cop
+        d.mul_z = d.mul_y = d.mul_x = 1
+        d.step_z = d.step_y = d.step_x = -1
+        d.n_img, d.N = B, N
+        d.x_bytes = gy.bytes_left
+        d.y, d.y_ld, d.y_D, d.y_H, d.y_W = gx.ptr, gx.ld, idims[0], idims[1], idims[2]
+        d.y_mul_z, d.y_mul_y, d.y_mul_x = self.stride
+        d.slope, d.dtype, d.accumulate = slope, self.ws.code, int(accumulate)
+        d.n_cls = len(live)
+        for i, (k, g) in enumerate(live):
+            c = d.cls[i]
+            c.taps_z, c.taps_y, c.taps_x = k["nt"]
+            c.off_z, c.off_y, c.off_x = k["c"]
+            c.g_D, c.g_H, c.g_W = g
+            c.y_off_z, c.y_off_y, c.y_off_x = k["par"]
+            c.w, c.w_ld, c.w_bytes = k["pack"].data_ptr(), k["pack"].shape[1], k["pack"].numel() * k["pack"].element_size()
+        # the launch's own class fields = class 0 (descriptor validation reads them)
+        d.taps_z, d.taps_y, d.taps_x = k0["nt"]
+        d.off_z, d.off_y, d.off_x = k0["c"]
+        d.g_D, d.g_H, d.g_W = g0
+        d.y_off_z, d.y_off_y, d.y_off_x = k0["par"]
+        d.w, d.w_ld, d.w_bytes = d.cls[0].w, d.cls[0].w_ld, d.cls[0].w_bytes
+        bn = 128 if N > 64 else (64 if N > 32 else 32)
+        tiles = ((M + 127) // 128) * ((N + bn - 1) // bn) * len(live)
+        nk = (Kmin + 31) // 32
+        d.algo, d.tile_n, d.split_k = 1, 0, 1
+        if tiles < 256 and nk >= 16:
+            split = max(1, min((512 + tiles - 1) // tiles, nk // 4, 64))
+            if split > 1:
+                d.split_k, d.slab_cls_stride = split, split * M * N
+                self.ws.need_scratch(len(live) * split * M * N)
+                d.slab = self.ws.get_scratch().data_ptr()
+        PROFILER.launch("mireg_conv_gemm", d, "conv3d_gemm", 2.0 * sum(m * N * kk for m, kk in zip(Ms, Ks)),
+                        f"{getattr(self, 'name', 'conv3d')} dgrad {len(live)} classes M<={M} N={N}")
+        return True
 
     def wgrad(self, x, idims: Tuple[int, int, int], gy, odims: Tuple[int, int, int]) -> None:
         """slab[z][co][(tz,ty,tx)*Cip + ci] = sum_voxels gy[v][co] x[v @ tap][ci]: one backward-weights launch per depth tap,

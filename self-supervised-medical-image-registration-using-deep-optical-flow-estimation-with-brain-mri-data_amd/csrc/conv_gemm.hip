@@ -108,6 +108,7 @@ conv_gemm_dma_kernel(const mireg_conv_desc pd) {
     const mireg_conv_cls k = pd.cls[cls];
     p.taps_y = k.taps_y; p.taps_x = k.taps_x; p.off_y = k.off_y; p.off_x = k.off_x; p.g_H = k.g_H; p.g_W = k.g_W;
     p.y_off_y = k.y_off_y; p.y_off_x = k.y_off_x; p.w = k.w; p.w_ld = k.w_ld; p.w_bytes = k.w_bytes;
+    if (k.g_D > 0) { p.taps_z = k.taps_z; p.off_z = k.off_z; p.g_D = k.g_D; p.y_off_z = k.y_off_z; }      // Conv3d parity classes
   }
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -425,6 +426,7 @@ splitk_reduce_kernel(const mireg_conv_desc pd) {
   if (pd.n_cls > 1) {
     const mireg_conv_cls k = pd.cls[blockIdx.y];
     p.g_H = k.g_H; p.g_W = k.g_W; p.y_off_y = k.y_off_y; p.y_off_x = k.y_off_x;
+    if (k.g_D > 0) { p.g_D = k.g_D; p.y_off_z = k.y_off_z; }
   }
   const float* __restrict__ slab = p.slab + (long)blockIdx.y * pd.slab_cls_stride;
   const int gD = max(p.g_D, 1), yD = max(p.y_D, 1), ymz = max(p.y_mul_z, 1);
@@ -909,7 +911,8 @@ long largest_class_rows(const mireg_conv_desc& p) {
   const int ncls = p.n_cls > 1 ? p.n_cls : 1;
   long M = 0;
   for (int c = 0; c < ncls; ++c) {
-    const long m = (ncls > 1 ? (long)p.n_img * p.cls[c].g_H * p.cls[c].g_W : (long)p.n_img * p.g_H * p.g_W) * (p.g_D > 0 ? p.g_D : 1);
+    const long m = (ncls > 1 ? (long)p.n_img * p.cls[c].g_H * p.cls[c].g_W * (p.cls[c].g_D > 0 ? p.cls[c].g_D : (p.g_D > 0 ? p.g_D : 1))
+                             : (long)p.n_img * p.g_H * p.g_W * (p.g_D > 0 ? p.g_D : 1));
     M = m > M ? m : M;
   }
   return M;
@@ -920,7 +923,8 @@ int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
   const int ncls = p.n_cls > 1 ? p.n_cls : 1;
   long M = 0;                                                       // largest class decides the grid
   for (int c = 0; c < ncls; ++c) {
-    const long m = (ncls > 1 ? (long)p.n_img * p.cls[c].g_H * p.cls[c].g_W : (long)p.n_img * p.g_H * p.g_W) * (p.g_D > 0 ? p.g_D : 1);
+    const long m = (ncls > 1 ? (long)p.n_img * p.cls[c].g_H * p.cls[c].g_W * (p.cls[c].g_D > 0 ? p.cls[c].g_D : (p.g_D > 0 ? p.g_D : 1))
+                             : (long)p.n_img * p.g_H * p.g_W * (p.g_D > 0 ? p.g_D : 1));
     M = m > M ? m : M;
   }
   const int z = p.split_k > 1 ? p.split_k : 1;
@@ -969,7 +973,7 @@ bool desc_ok(const mireg_conv_desc* p, bool wgrad) {
   if (wgrad) {
     if (!p->y || !p->slab || p->y_ld % cpc || ((uintptr_t)p->y % 16)) return false;
   } else {
-    if (p->n_cls < 0 || p->n_cls > 4) return false;
+    if (p->n_cls < 0 || p->n_cls > 8) return false;
     if (p->n_cls <= 1 && (!p->w || p->w_ld % cpc || ((uintptr_t)p->w % 16) || p->w_bytes <= 0 || p->w_bytes >= (1L << 31))) return false;
     if (p->x_bytes <= 0 || p->x_bytes >= (1L << 31)) return false;
     for (int c = 0; c < (p->n_cls > 1 ? p->n_cls : 0); ++c)

@@ -427,6 +427,8 @@ extern "C" int mireg_conv_halo_eligible(const mireg_conv_desc* p, long* tiles_ou
   if (!p || p->split_k > 1 || p->y32 || !p->y) return 0;
   if (p->mul_y != 1 || p->mul_x != 1 || abs(p->step_y) != 1 || abs(p->step_x) != 1) return 0;
   if (p->x_D > 1 || p->g_D > 1 || p->taps_z > 1 || p->y_D > 1 || p->off_z != 0 || p->y_off_z != 0) return 0;
+  if (p->n_cls > 4) return 0;
+  for (int c = 0; c < (p->n_cls > 1 ? p->n_cls : 0); ++c) if (p->cls[c].g_D > 0) return 0;
   if (p->N < 32) return 0;                                  // a 64-column tile half full still beats the ring kernel's im2col traffic (PWC's 32-channel layers)
   if (p->dtype != MIREG_DTYPE_BF16 && p->dtype != MIREG_DTYPE_F32) return 0;
   const int ncls = p->n_cls > 1 ? p->n_cls : 1;

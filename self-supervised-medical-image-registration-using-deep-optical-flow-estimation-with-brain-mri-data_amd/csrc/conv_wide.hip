@@ -416,7 +416,7 @@ extern "C" int mireg_conv_wide_eligible(const mireg_conv_desc* p, long* tiles_ou
   if (tiles_out) *tiles_out = 0;
   if (!p || p->dtype != MIREG_DTYPE_BF16) return 0;
   const bool depth = p->x_D > 1 || p->g_D > 1 || p->taps_z > 1 || p->y_D > 1;
-  if (depth && p->n_cls > 1) return 0;                               // Conv3d backward-data: one launch per parity class
+  if ((depth && p->n_cls > 1) || p->n_cls > 4) return 0;             // Conv3d parity classes in one launch: ring kernel only
   if (p->x_C < 64 || p->N < 16) return 0;
   const int ncls = p->n_cls > 1 ? p->n_cls : 1;
   long M = 0;

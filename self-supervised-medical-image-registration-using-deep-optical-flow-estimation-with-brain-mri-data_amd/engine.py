@@ -32,6 +32,7 @@ def rup(v: int, m: int) -> int:
 class ConvCls(ctypes.Structure):
     _fields_ = [("taps_y", ctypes.c_int), ("taps_x", ctypes.c_int), ("off_y", ctypes.c_int), ("off_x", ctypes.c_int),
                 ("g_H", ctypes.c_int), ("g_W", ctypes.c_int), ("y_off_y", ctypes.c_int), ("y_off_x", ctypes.c_int),
+                ("taps_z", ctypes.c_int), ("off_z", ctypes.c_int), ("g_D", ctypes.c_int), ("y_off_z", ctypes.c_int),
                 ("w", ctypes.c_void_p), ("w_ld", ctypes.c_long), ("w_bytes", ctypes.c_long)]
 
 
@@ -47,7 +48,7 @@ class ConvDesc(ctypes.Structure):
                 ("y32", ctypes.c_void_p), ("y32_ld", ctypes.c_long),
                 ("bias", ctypes.c_void_p), ("slope", ctypes.c_float), ("accumulate", ctypes.c_int), ("dtype", ctypes.c_int),
                 ("split_k", ctypes.c_int), ("slab", ctypes.c_void_p), ("x_bytes", ctypes.c_long), ("w_bytes", ctypes.c_long),
-                ("n_cls", ctypes.c_int), ("cls", ConvCls * 4), ("slab_cls_stride", ctypes.c_long),
+                ("n_cls", ctypes.c_int), ("cls", ConvCls * 8), ("slab_cls_stride", ctypes.c_long),
                 ("x_D", ctypes.c_int), ("taps_z", ctypes.c_int), ("mul_z", ctypes.c_int), ("off_z", ctypes.c_int),
                 ("step_z", ctypes.c_int), ("g_D", ctypes.c_int), ("y_D", ctypes.c_int), ("y_mul_z", ctypes.c_int),
                 ("y_off_z", ctypes.c_int), ("tile_n", ctypes.c_int), ("stages", ctypes.c_int), ("slab_ld", ctypes.c_long),
