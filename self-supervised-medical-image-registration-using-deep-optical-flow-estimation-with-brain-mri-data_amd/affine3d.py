@@ -71,7 +71,7 @@ def _vol(x, dims) -> Vol:
     return x if isinstance(x, Vol) else Vol(x, tuple(dims), x.shape[-1], 0)
 
 
-MERGE_ALWAYS = os.environ.get("MIREG_3D_DGRAD_MERGE_ALWAYS", "0") == "1"        # experiment: also where the per-class launches take the 8-wave tile
+WIDE_CLASSES = os.environ.get("MIREG_3D_DGRAD_WIDE_CLASSES", "0") == "1"        # A/B switch: large levels as per-class launches of the 8-wave tile
 MERGE_CLASSES = os.environ.get("MIREG_3D_DGRAD_PER_CLASS", "0") != "1"     # A/B switch: one backward-data launch per parity class
 WGRAD_PER_TAP = os.environ.get("MIREG_3D_WGRAD_PER_TAP", "0") == "1"    # A/B switch: one backward-weights launch per depth tap
 FORCE_WIDE = None      # tests only: None = heuristic, (128,) / (256,) = always the 256-pixel tile at that width, () = never
@@ -242,16 +242,17 @@ class Conv3dLayer:
 
     def _merged_dgrad(self, live, gy: Vol, odims, gx: Vol, idims, slope: float, accumulate: bool) -> bool:
         """All parity classes of a stride-2 backward-data pass in ONE ring-kernel launch (blockIdx.y = class, mireg_conv_cls with its
-        depth fields) plus one split-K reduce, instead of up to eight of each: the coarse levels' launches are launch-latency sized.
-        Not where the per-class launches take the 8-wave tile (large levels; that kernel runs one class per launch): returns False."""
+        depth fields) plus one split-K reduce, instead of up to eight of each: the coarse levels' launches are launch-latency sized and
+        the large levels' eight grids (27 / 18 / 12 / 8 taps) leave CUs idle at each launch's tail.  False = take the per-class path."""
         B, Cop, N = gy.B, rup(self.Co, 8), self.Ci
         Ms = [B * g[0] * g[1] * g[2] for _, g in live]
         Ks = [k["pack"].shape[1] for k, _ in live]
         M, Kmin = max(Ms), min(Ks)
-        if self.ws.code == DT_BF16 and engine_mod.USE_WIDE and FORCE_WIDE != () and Cop >= 64 and N >= 16 and min(Ks) >= 64:
-            t256, t128 = ((M + 255) // 256) * ((N + 255) // 256), ((M + 255) // 256) * ((N + 127) // 128)
-            if (FORCE_WIDE or (N > 128 and t256 >= 224) or t128 >= 224) and not MERGE_ALWAYS:
-                return False
+        # (measured, FlowNetS-3D: the merged launch also beats eight launches of the 8-wave tile on the large levels, 12.62 -> 12.25 ms per
+        # step; WIDE_CLASSES restores the per-class form there, FORCE_WIDE (tests) always takes it)
+        if FORCE_WIDE or (WIDE_CLASSES and self.ws.code == DT_BF16 and engine_mod.USE_WIDE and FORCE_WIDE != () and Cop >= 64 and N >= 16
+                          and min(Ks) >= 64 and (((M + 255) // 256) * ((N + 127) // 128) >= 224)):
+            return False
         k0, g0 = live[0]
         d = ConvDesc()
         d.x, d.x_ld, d.x_D, d.x_H, d.x_W, d.x_C = gy.ptr, gy.ld, odims[0], odims[1], odims[2], Cop
