@@ -14,6 +14,7 @@
 // XOR-swizzled on the source side and on the ds_read_b128 side (bank-conflict free); counted vmcnt, one raw s_barrier
 // per K-step.  Unit-stride gathers whose grid is 16/32/64 pixels wide take the halo-staged kernel of conv_halo.hip instead
 // (each input pixel staged once per channel chunk, not once per tap); this file keeps the strided and small-grid cases.
+#include <cstdlib>
 #include "mireg_common.h"
 #include "../../include/mireg.h"
 #include <stdlib.h>
@@ -664,11 +665,14 @@ conv_wgrad_kernel(const mireg_conv_desc p) {
 // =====================================================================================================
 // STAGES = 3: with the two-pass epilogue the kernel needs 48 KiB of LDS, so three workgroups share a CU -- split-K launches
 // have 700-800 workgroups, which then are all resident at once (conv2's wgrad: 90 -> 69 us); 4 stages gain nothing elsewhere.
-template <typename T, int STAGES = 3>
+// NARROW: layers with few output channels (PWC's 32 / 64-channel dense layers, conv1 of FlowNetS over volumes) fill a quarter / half of
+// the 128 tile rows.  Same LDS tiles and DMA schedule, but the four waves then sit side by side over the 128 columns and own only the
+// real rows -- NARROW 1: 64 rows x 32 columns per wave (half the MFMAs and fragment reads), NARROW 2: 32 x 32 (a quarter).
+template <typename T, int STAGES = 3, int NARROW = 0>
 __global__ void __launch_bounds__(256)
 conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   constexpr int CPC = Cfg<T>::CPC, BK = Cfg<T>::BK, BM = 128, BN = 128;
-  constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2;
+  constexpr int WTM = NARROW == 2 ? 32 : 64, WTN = NARROW ? 32 : 64, TM = NARROW == 2 ? 1 : 2, TN = NARROW ? 1 : 2;
   constexpr int ROWB = 128 * (int)sizeof(T);                     // bytes per pixel row of a tile
   constexpr int RPI = 1024 / ROWB;                               // pixel rows per DMA instruction (4 bf16 / 2 fp32)
   constexpr int CPR = ROWB / 16;                                 // 16-B chunks per row (16 / 32)
@@ -681,7 +685,7 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = NARROW ? 0 : wid >> 1, wn = NARROW ? wid : wid & 1;
   const int r = lane & 31, h = lane >> 5;
   const int Ktot = p.taps_y * p.taps_x * p.x_C;                  // GEMM N
   const int tiles_n = (Ktot + BN - 1) / BN;
@@ -874,7 +878,7 @@ conv_wgrad_dma_kernel(const mireg_conv_desc p) {
   const long sld = p.slab_ld > 0 ? p.slab_ld : Ktot;               // Conv3d: the depth taps share one [Cout][taps_z*Ktot] slab
   float* __restrict__ slab = p.slab + (long)blockIdx.z * Cout * sld + (long)blockIdx.y * Ktot;   // depth tap t fills columns [t*Ktot, (t+1)*Ktot)
   const bool vec = (Ktot % 4) == 0 && (sld % 4) == 0;
-  for (int hp = 0; hp < 2; ++hp) {                                  // rows [64 hp, 64 hp + 64) of the tile
+  for (int hp = 0; hp < (NARROW ? 1 : 2); ++hp) {                   // rows [64 hp, 64 hp + 64) of the tile (NARROW: the real rows only)
     if (hp) __syncthreads();
     if (wm == hp) {
 #pragma unroll
@@ -943,6 +947,9 @@ int launch_fwd(const mireg_conv_desc& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? MIREG_OK : MIREG_ERR_LAUNCH;
 }
 
+// MIREG_WGRAD_WIDE_ROWS=1 (environment, read once): A/B switch that keeps layers with <= 64 output channels on the 2 x 2 wave layout
+static const bool kWgradWideRows = [] { const char* e = getenv("MIREG_WGRAD_WIDE_ROWS"); return e && e[0] == '1'; }();
+
 template <typename T>
 int launch_wgrad(const mireg_conv_desc& p, hipStream_t stream) {
   const int Cout = p.N;
@@ -953,7 +960,9 @@ int launch_wgrad(const mireg_conv_desc& p, hipStream_t stream) {
   dim3 grid((unsigned)(((Cout + 127) / 128) * ((Ktot + 127) / 128)), (unsigned)(p.taps_z > 1 ? p.taps_z : 1), z);
   if (p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < (1L << 31) && p.w_bytes < (1L << 31))
     // 3 stages = 48 KiB LDS, three workgroups per CU; 4 stages = 64 KiB, two per CU (leaves more of the CU to a concurrent stream)
-    if (p.stages == 4) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 4>), grid, dim3(256), 0, stream, p);
+    if (Cout <= 32 && !kWgradWideRows) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 3, 2>), grid, dim3(256), 0, stream, p);
+    else if (Cout <= 64 && !kWgradWideRows) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 3, 1>), grid, dim3(256), 0, stream, p);
+    else if (p.stages == 4) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 4>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, 3>), grid, dim3(256), 0, stream, p);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, stream, p);
