@@ -299,9 +299,12 @@ def main():
             hsh = hashlib.sha1(b"".join(open(os.path.join(csrc, f), "rb").read() for f in sorted(os.listdir(csrc))
                                         if (f.startswith("conv_") and f.endswith(".hip")) or f == "mireg_common.h")).hexdigest()[:12]
             key = {"conv_wgrad_kernel<128,128>": "conv_wgrad_dma_kernel", "conv_wgrad_halo_kernel": "conv_wgrad_halo"}.get(dom[0], dom[0].split("<")[0])
-            ent = next((v for k, v in pmc["kernels"].items() if key in k), None)
+            ents = [v for k, v in pmc["kernels"].items() if key in k]            # every instantiation of the kernel (e.g. its narrow-Cout layouts)
+            ent = ents[0] if ents else None
             if ent is not None and pmc.get("csrc_sha1") == hsh and args.model == "flownets" and args.batch == 24 and args.size == 256:
-                rd, wr = ent["TCC_EA0_RDREQ_sum"]["mean_per_launch"], ent["TCC_EA0_WRREQ_sum"]["mean_per_launch"]
+                nl = sum(v["TCC_EA0_RDREQ_sum"]["launches"] for v in ents)
+                rd = sum(v["TCC_EA0_RDREQ_sum"]["mean_per_launch"] * v["TCC_EA0_RDREQ_sum"]["launches"] for v in ents) / nl
+                wr = sum(v["TCC_EA0_WRREQ_sum"]["mean_per_launch"] * v["TCC_EA0_WRREQ_sum"]["launches"] for v in ents) / nl
                 roof["traffic"] = round(2 * rd * 64 + wr * 64)
                 roof["traffic_note"] = f"bytes per launch, mean over the step's launches of {key}, from profiles/round3_pmc_conv_kernels.json (csrc sha1 {hsh})"
             else:
