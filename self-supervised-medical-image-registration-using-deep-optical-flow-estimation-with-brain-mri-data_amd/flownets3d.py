@@ -327,9 +327,23 @@ class FlowNetS3D(nn.Module):
             wgrad(dec, gdec, dims[lv], below, dims[lv + 1])
         # ---- encoder, deep to shallow ----
         prev = {n: (ENC[i - 1][0] if i else None) for i, (n, _, _) in enumerate(ENC)}
+        # BatchNorm scale / shift gradients: where the parameter already has a `.grad` (mireg.Adam.zero_grad keeps and zeroes them) the kernel
+        # adds into it directly and autograd gets None -- otherwise every step pays a copy into a hand-over buffer plus AccumulateGrad's add
+        # for each of the 20 small tensors (0.2 ms of launch-sized kernels on the serial chain)
+        direct = set()
+        # (single process only: DistributedDataParallel reduces a gradient when autograd hands it over, which this shortcut skips)
+        solo = not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)
+        own = e.setdefault("bn_own", {n: (b.grad_g, b.grad_b) for n, b in e["bns"].items()})
+        for name, _, _ in ENC:
+            mod, b = getattr(self, name)[1], e["bns"][name]
+            gw, gb = mod.weight.grad, mod.bias.grad
+            ok = solo and all(g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == dev for g in (gw, gb))
+            b.grad_g, b.grad_b = (gw, gb) if ok else own[name]
+            if ok:
+                direct.add(name)
         for name, k, s in reversed(ENC):
             lay, bn = L[name], e["bns"][name]
-            bn.backward(e["raw"][name].view2d(), gact[name].view2d(), e["graw"][name].view2d())
+            bn.backward(e["raw"][name].view2d(), gact[name].view2d(), e["graw"][name].view2d(), acc_param_grads=name in direct)
             src = act[prev[name]] if prev[name] else e["x0"]
             odims = e["raw"][name].dims
             wgrad(lay, src, src.dims, e["graw"][name], odims)
@@ -369,6 +383,9 @@ class FlowNetS3D(nn.Module):
                 pairs.append((conv_of[pname], g))
             else:                                                                    # BatchNorm3d weight / bias
                 lname, _, kind = pname.split(".")
+                if lname in direct:                                                  # already added into p.grad by the kernel
+                    grads.append(None)
+                    continue
                 g = gb(pname, p, p)
                 g.copy_(e["bns"][lname].grad_g if kind == "weight" else e["bns"][lname].grad_b)
             grads.append(g)
