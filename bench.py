@@ -444,7 +444,7 @@ def main():
                 loss.backward()
                 opt_f.step()
                 return loss.detach()      # a live loss keeps last step's AccumulateGrad nodes (and their stream) alive, which breaks capture
-            t3, l3 = timed(f3_train, 3, warm=1)
+            t3, l3 = timed(f3_train, 6, warm=3)
             PROFILER.enabled, PROFILER.records, PROFILER.byte_records = True, [], []
             f3_train()
             s3 = PROFILER.summary()
