@@ -803,7 +803,8 @@ class ConvLayer:
             self.grad_b = torch.zeros_like(self.bias, dtype=F32)
         if self.ws.colsum_ws is None or self.ws.colsum_ws.numel() < 64 * dy.C:
             self.ws.colsum_ws = torch.empty(64 * max(dy.C, 1024), device=self.ws.device, dtype=F32)
-        _lib.call("mireg_colsum", dy.ptr, dy.ld, dy.rows, dy.C, self.grad_b.data_ptr(), int(accumulate),
+        # bias_direct: grad_b IS the parameter's .grad for this backward (PredictorEngineBase.autograd_backward): always add into it
+        _lib.call("mireg_colsum", dy.ptr, dy.ld, dy.rows, dy.C, self.grad_b.data_ptr(), int(accumulate or getattr(self, "bias_direct", False)),
                   self.ws.colsum_ws.data_ptr(), self.ws.code,
                   _stream())
 
@@ -836,7 +837,7 @@ class BatchNormAct:
     def backward(self, y: View, da: View, dy: View, acc_param_grads: bool = False) -> None:
         _lib.call("mireg_bn_backward", y.ptr, y.ld, da.ptr, da.ld, dy.ptr, dy.ld, self.ss.data_ptr(),
                   self.partial.data_ptr(), self.red.data_ptr(), self.grad_g.data_ptr(), self.grad_b.data_ptr(),
-                  int(acc_param_grads), y.rows,
+                  int(acc_param_grads or getattr(self, "direct", False)), y.rows,
                   self.C, self.slope, self.ws.code, _stream())
 
 

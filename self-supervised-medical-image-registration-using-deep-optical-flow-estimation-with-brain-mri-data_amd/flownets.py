@@ -18,6 +18,7 @@ from . import engine as engine_mod
 from .engine import (DT_BF16, F32, TINY_MASK, BatchNormAct, ConvLayer, View, WoptJob, Workspace, _stream, assign_tiles, cast_from_f32, zero_tensors,
                      lrelu_bwd, nchw_to_view, upload_table)
 
+DIRECT_SMALL_GRADS = os.environ.get("MIREG_HANDOVER_SMALL_GRADS", "0") != "1"   # A/B switch: bias / BatchNorm gradients through AccumulateGrad
 FORK_DECODER = os.environ.get("MIREG_SERIAL_DECODER", "0") != "1"   # A/B switch: decoder heads next to the deconvolutions
 
 ENCODER = [  # name, cin, cout, k, stride   (FlowNetS/FlowNetS.py:17-26)
@@ -330,15 +331,46 @@ class PredictorEngineBase:
             raise RuntimeError("a second backward before optimizer.step(): with mireg.Adam(fuse=...) the weight gradients live in the "
                                "backward-weights slabs, which one backward fills and one step consumes")
         mode, self.grad_mode, self.fused_index = self.grad_mode, "torch", fused
+        bound = self._bind_small_grads() if (DIRECT_SMALL_GRADS and mode == "torch") else []
         try:
             self.backward(g)
             self.slab_pending = fused is not None
         finally:
             self.grad_mode = mode
+            for obj, attr, val, flag in bound:                 # the engine's own buffers again (eval / trainer paths use them)
+                setattr(obj, attr, val)
+                setattr(obj, flag, False)
         if fused is not None:                                  # torch-layout weight gradients are not produced in this mode
             for l in self.layers.values():
                 if id(l.weight) in fused:
                     l.grad_w = None
+
+    def _bind_small_grads(self) -> list:
+        """Bias and BatchNorm gradients of this backward go straight into the parameters' `.grad` where one exists (mireg.Adam.zero_grad
+        keeps and zeroes them): the kernels add into it, `param_grads()` leaves those parameters out and autograd gets None for them.
+        Otherwise every step pays AccumulateGrad's add for each of the few hundred small tensors of a stack like FlowNet2 (launch-sized
+        kernels on the serial chain).  Single process only: DistributedDataParallel reduces a gradient when autograd hands it over."""
+        self._direct_ids = set()
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            return []
+        dev, bound = self.ws.device, []
+
+        def usable(p):
+            g = p.grad
+            return g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == dev
+        for l in self.layers.values():
+            if l.bias is not None and usable(l.bias):
+                bound.append((l, "grad_b", l.grad_b, "bias_direct"))
+                l.grad_b, l.bias_direct = l.bias.grad, True
+                self._direct_ids.add(id(l.bias))
+        for b in self.bns.values():
+            w, bi = b.bn.weight, b.bn.bias
+            if usable(w) and usable(bi):                       # (siamese streams: two objects over one BatchNorm module, both add into its .grad)
+                bound.append((b, "grad_g", b.grad_g, "direct"))
+                bound.append((b, "grad_b", b.grad_b, "direct"))
+                b.grad_g, b.grad_b, b.direct = w.grad, bi.grad, True
+                self._direct_ids.update((id(w), id(bi)))
+        return bound
 
     def fused_adam(self, opt, tick: int) -> None:
         """Slabs -> (in-place slab sum) -> Adam on the fp32 master weights + refreshed forward packs (`mireg_adam_pack`), then the
@@ -389,6 +421,8 @@ class PredictorEngineBase:
         for b in self.bns.values():
             out[id(b.bn.weight)] = b.grad_g
             out[id(b.bn.bias)] = b.grad_b
+        for i in getattr(self, "_direct_ids", ()):              # already added into .grad by the last autograd_backward
+            out.pop(i, None)
         return out
 
 
