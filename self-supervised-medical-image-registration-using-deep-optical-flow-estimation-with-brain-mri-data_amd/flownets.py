@@ -143,10 +143,17 @@ class PredictorEngineBase:
         ev.record(torch.cuda.current_stream())
         return ev
 
-    _MAIN_ONLY = tuple(t for t in os.environ.get("MIREG_WGRAD_ON_MAIN", "").split(",") if t)   # experiments: layer-name prefixes kept off the side stream
+    # layer-name prefixes whose backward-weights launches stay on the main stream.  The flow heads': their gather + 18-column GEMM pairs
+    # made the backward-weights stream the long pole of the decoder phase (the main chain then idled ~140 us at the phase join);
+    # measured on FlowNetS: 2.695 -> 2.615 ms per step.  (Also tried: the 2 -> 2 upsamplers, the deconvolutions, conv6: each slower.)
+    # Measured per predictor (default bench, one box): FlowNetS in the fused trainer gains, FlowNetC / PWC / the FlowNet2 stack lose 1-2 %,
+    # so only FlowNetSEngine under the trainer sets it (main_only_default); MIREG_WGRAD_ON_MAIN overrides for experiments.
+    _MAIN_ONLY = (tuple(t for t in os.environ["MIREG_WGRAD_ON_MAIN"].split(",") if t) if "MIREG_WGRAD_ON_MAIN" in os.environ else None)
+    main_only_default: tuple = ()
 
     def wgrad_async(self, lay: ConvLayer, x: View, dy: View, slot: int = 0, after=None) -> None:
-        if not self.use_side_stream or (self._MAIN_ONLY and lay.name.startswith(self._MAIN_ONLY)):
+        main_only = self._MAIN_ONLY if self._MAIN_ONLY is not None else self.main_only_default
+        if not self.use_side_stream or (main_only and lay.name.startswith(main_only)):
             lay.run_wgrad(x, dy, slot)
             return
         if getattr(self, "_side", None) is None:
@@ -576,6 +583,10 @@ class FlowNetDecoderMixin:
 
 
 class FlowNetSEngine(PredictorEngineBase, FlowNetDecoderMixin):
+    @property
+    def main_only_default(self) -> tuple:
+        return ("predict_flow",) if self.grad_mode == "packed" else ()
+
     def __init__(self, module: "FlowNetS", B: int, H: int, W: int, device, dtype: torch.dtype):
         super().__init__(module, B, H, W, device, dtype)
         if H % 64 or W % 64:
