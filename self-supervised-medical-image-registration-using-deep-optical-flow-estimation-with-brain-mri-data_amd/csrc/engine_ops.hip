@@ -5,6 +5,7 @@
 //   fused Adam exactly as train.py:129 configures it (eps = 1e-4).
 // Every kernel streams 16-byte vectors through GLOBAL (address-space 1) accesses; reductions are two-stage
 // (per-block partial rows, then a tiny finalize) so they are deterministic and free of atomic contention.
+#include <cstdlib>
 #include "mireg_common.h"
 #include "../../include/mireg.h"
 
@@ -825,6 +826,8 @@ adam_pack_kernel(const mireg_wopt_job* __restrict__ jobs, int njobs, const int* 
 }
 
 constexpr long kBnFusedMaxRows = 2048;   // rows up to which BatchNorm runs as one launch (deep layers)
+// backward reads two tensors per pass: at 1,536 rows the one-launch form (C/16 = 32 blocks) takes 29-33 us as run, three launches ~18
+static const long kBnFusedMaxRowsBwd = [] { const char* e = getenv("MIREG_BN_FUSED_BWD_ROWS"); return e ? atol(e) : 512L; }();
 
 inline int grid1(long work, int cap = 4096) {
   long g = (work + 255) / 256;
@@ -958,7 +961,7 @@ int mireg_bn_backward(const void* y, long ld_y, const void* da, long ld_da, void
   MIREG_CHECK_ARG(y && da && dy && ss && partial && red && M > 0 && C > 0 && C <= 4096);
   const bool vec = vec_ok(dtype, C, {ld_y, ld_da, ld_dy}, {y, da, dy});
   const int nblk = bn_blocks(M, C, dtype, vec);
-  if (vec && M <= kBnFusedMaxRows) {
+  if (vec && M <= kBnFusedMaxRowsBwd) {
     const int V = dtype == MIREG_DTYPE_BF16 ? 8 : 4, blocks = (C / V + 1) / 2;
     float* ssm = const_cast<float*>(ss);
     if (dtype == MIREG_DTYPE_BF16)
