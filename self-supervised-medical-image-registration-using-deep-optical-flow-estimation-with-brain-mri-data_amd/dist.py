@@ -13,7 +13,7 @@ The functions below are backend-agnostic so the N>1 path is covered on CPU with 
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import Sequence
 
 import torch
 import torch.distributed as dist

@@ -15,9 +15,8 @@ from typing import Dict, List
 import torch
 import torch.nn as nn
 
-from . import _lib
 from .correlation import correlation_bwd_views, Correlation, correlation_views
-from .engine import BatchNormAct, F32, _stream, lrelu_bwd, nchw_to_view
+from .engine import BatchNormAct, lrelu_bwd, nchw_to_view
 from .flownets import (drop_engines, grads_for_autograd, PackedOptimizerHook, DECONV, ENCODER, PREDICT, SLOPE, FlowNetDecoderMixin, PredictorEngineBase, conv_block, count_bn_batches,
                        install_bn_counter_hook)
 

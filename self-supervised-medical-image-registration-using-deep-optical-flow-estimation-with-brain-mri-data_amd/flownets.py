@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import engine as engine_mod
-from .engine import (DT_BF16, F32, TINY_MASK, BatchNormAct, ConvLayer, View, WoptJob, Workspace, _stream, assign_tiles, cast_from_f32, zero_tensors,
+from .engine import (F32, TINY_MASK, BatchNormAct, ConvLayer, View, WoptJob, Workspace, _stream, assign_tiles, cast_from_f32, zero_tensors,
                      lrelu_bwd, nchw_to_view, upload_table)
 
 DIRECT_SMALL_GRADS = os.environ.get("MIREG_HANDOVER_SMALL_GRADS", "0") != "1"   # A/B switch: bias / BatchNorm gradients through AccumulateGrad

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import dist as mdist
-from .engine import PROFILER, AdamJob, F32, TailJob, WoptJob, _stream, upload_table, zero_tensors
+from .engine import PROFILER, AdamJob, F32, TailJob, _stream, upload_table, zero_tensors
 from .ops import SLOTS
 
 
