@@ -21,6 +21,7 @@ from .engine import BatchNormAct, WoptJob, Workspace, _stream, assign_tiles, rup
 from .volume import resize_trilinear, stn3d
 
 WGRAD_SIDE_STREAM = os.environ.get("MIREG_3D_WGRAD_MAIN", "0") != "1"
+SIDE_IN_GRAPH = os.environ.get("MIREG_3D_SIDE_IN_GRAPH", "0") == "1"          # experiment: backward-weights branch also inside a capture
 TINY_UPSAMPLERS = os.environ.get("MIREG_3D_GEMM_UPSAMPLERS", "0") != "1"      # A/B switch: the flow upsamplers on the GEMM path
 
 ENC = [("conv1", 7, 2), ("conv2", 5, 2), ("conv3", 5, 2), ("conv3_1", 3, 1), ("conv4", 3, 2), ("conv4_1", 3, 1),
@@ -280,7 +281,7 @@ class FlowNetS3D(nn.Module):
         # backward-weights launches go to a second stream (their inputs are final once the main chain reaches them, nothing on the main
         # chain reads their slabs before the join below): they fill the CUs the backward-data chain leaves idle on the coarse levels
         main = torch.cuda.current_stream()
-        use_side = WGRAD_SIDE_STREAM and not torch.cuda.is_current_stream_capturing()   # measured: as a graph branch it costs 0.3 ms
+        use_side = WGRAD_SIDE_STREAM and (SIDE_IN_GRAPH or not torch.cuda.is_current_stream_capturing())   # measured: as a graph branch it costs 0.3 ms
         side = e.get("side") if use_side else None
         if use_side and side is None:
             side = e["side"] = torch.cuda.Stream(device=dev)
